@@ -1,0 +1,142 @@
+"""ctypes binding of libmrcnn_hip.so (include/mrcnn_hip.h).
+
+The HIP library is the product: if it cannot be loaded, every op fails loudly —
+there is no CPU or eager-PyTorch fallback anywhere in this package.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmrcnn_hip.so')
+
+EPI_BIAS, EPI_AFFINE, EPI_RESIDUAL, EPI_RELU, EPI_ACCUM = 1, 2, 4, 8, 16
+
+c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    """mrcnn_conv_desc."""
+    _fields_ = [(k, c_int) for k in
+                ('N', 'H', 'W', 'C', 'K', 'R', 'S', 'stride', 'pad', 'P', 'Q')]
+
+
+_DP = ctypes.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol declared in include/mrcnn_hip.h
+SIGNATURES = {
+    'mrcnn_last_error': (ctypes.c_char_p, []),
+    'mrcnn_abi_version': (c_int, []),
+    'mrcnn_device_info': (c_int, [ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
+    'mrcnn_roi_align_fwd': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_f32, c_int, c_vp]),
+    'mrcnn_roi_align_bwd': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_f32, c_int, c_vp]),
+    'mrcnn_affine_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
+    'mrcnn_colsum_workspace_bytes': (c_i64, [c_int]),
+    'mrcnn_affine_bwd': (c_int, [c_vp] * 6 + [c_i64, c_int, c_vp, c_vp]),
+    'mrcnn_decode_clip': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_f32, c_vp]),
+    'mrcnn_topk_workspace_bytes': (c_i64, [c_int]),
+    'mrcnn_topk_desc': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'mrcnn_gather_rows': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    'mrcnn_nms_workspace_bytes': (c_i64, [c_int, c_int]),
+    'mrcnn_nms_sorted': (c_int, [c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'mrcnn_nms_sorted_batched': (c_int, [c_vp, c_vp, c_int, c_int, c_f32, c_int, c_vp, c_vp,
+                                         c_vp, c_vp]),
+    'mrcnn_conv2d_fwd': (c_int, [_DP] + [c_vp] * 7 + [c_int, c_vp]),
+    'mrcnn_conv2d_dgrad': (c_int, [_DP, c_vp, c_vp, c_vp, c_int, c_vp]),
+    'mrcnn_conv2d_wgrad_workspace_bytes': (c_i64, [_DP]),
+    'mrcnn_conv2d_wgrad': (c_int, [_DP, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'mrcnn_conv_stem_fwd': (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp]),
+    'mrcnn_deconv2x2s2_fwd': (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
+    'mrcnn_deconv2x2s2_dgrad': (c_int, [c_vp] * 3 + [c_int] * 5 + [c_vp]),
+    'mrcnn_deconv2x2s2_wgrad_workspace_bytes': (c_i64, [c_int] * 5),
+    'mrcnn_deconv2x2s2_wgrad': (c_int, [c_vp] * 3 + [c_int] * 5 + [c_vp, c_vp]),
+    'mrcnn_epilogue_bwd': (c_int, [c_vp] * 4 + [c_i64, c_int, c_vp]),
+    'mrcnn_colsum': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
+    'mrcnn_maxpool3x3s2p1_fwd': (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp]),
+    'mrcnn_avgpool_fwd': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'mrcnn_avgpool_bwd': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    'mrcnn_loss_workspace_bytes': (c_i64, [c_int]),
+    'mrcnn_sigmoid_ce': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    'mrcnn_mask_sigmoid_ce': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp,
+                                      c_vp]),
+    'mrcnn_softmax_ce': (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp,
+                                 c_vp]),
+    'mrcnn_smooth_l1': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_vp, c_vp,
+                                c_vp]),
+    'mrcnn_softmax': (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+    'mrcnn_sgd_momentum_wd': (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
+                                      c_vp]),
+    'mrcnn_decode_cls_boxes': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_f32,
+                                       ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), c_f32,
+                                       c_f32, c_vp]),
+}
+
+_lib = None
+
+
+class MrcnnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmrcnn_hip.so (built by ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MrcnnHipError(
+            'libmrcnn_hip.so not found at %s — build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` or '
+            '`make -C chainer_mask_rcnn_amd/csrc`. There is no fallback path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().mrcnn_last_error()
+        raise MrcnnHipError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def call(name, *args):
+    """Call an int-returning entry point on the current stream; raise on error."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MrcnnHipError(
+                'chainer_mask_rcnn_amd ops run only on a ROCm device tensor '
+                '(got a %s tensor); there is no CPU path.' % t.device)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag='default'):
+    """Caller-owned scratch, cached per (device, tag); grows monotonically."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -1,0 +1,593 @@
+// fp32 implicit-GEMM convolution family on MFMA for gfx950 (NHWC / KRSC).
+//
+// Replaces every cuDNN call the reference makes through chainer's
+// L.Convolution2D / L.Deconvolution2D / L.Linear and their backward passes
+// (call sites /root/reference/chainer_mask_rcnn/models/region_proposal_network.py:75-80,
+// models/mask_rcnn_resnet.py:131-143, chainer ResNet50Layers via
+// models/resnet_extractor.py:93), plus the AffineChannel2D + residual + ReLU that
+// follow each conv inside chainer's BottleneckA/B (fused into the epilogue here).
+//
+// One kernel body, three operand-gather modes:
+//   FWD    y[m, k]   = sum_{r,s,c} x[pix(m,r,s), c] * w[k, r, s, c]
+//   DGRAD  gx[m, c]  = sum_{r,s,k} gy[pix'(m,r,s), k] * w[k, r, s, c]
+//   WGRAD  gw[k, rsc] = sum_m gy[m, k] * x[pix(m,r,s), c]      (split over m)
+// All arithmetic is exact fp32 on v_mfma_f32_32x32x2_f32 (157 TF/s peak; there is
+// no TF32/xf32 on gfx950), so results are fp32-roundoff-close to a CPU fp32 GEMM.
+//
+// Tiling (wave64): 256 threads = 2x2 waves, each wave owns TM x TN MFMA tiles of
+// 32x32 (TM=TN=2 -> 128x128 block tile; TM=TN=1 -> 64x64 for small problems).
+// K is consumed in 32-deep slices staged global -> registers -> LDS
+// (double-buffered, one barrier per slice).  Operands whose K index is
+// contiguous in memory sit in LDS as [row][32+4] and are fetched with one
+// ds_read_b128 per 4 MFMAs; operands whose K index is the strided one sit as
+// [k][row] and are fetched with conflict-free ds_read_b32.  Inside an 8-deep
+// K block MFMA step t pairs k = 4*half + t of both operands (any pairing is
+// valid as long as A and B agree).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int KPAD = 4;  // K-contiguous LDS rows are 36 floats (conflict-free b128)
+
+enum Mode { FWD = 0, DGRAD = 1, WGRAD = 2 };
+enum OutMode { OUT_PLAIN = 0, OUT_STRIDED = 1, OUT_DECONV = 2 };
+
+struct GemmParams {
+    const float *A;      // FWD: x      DGRAD: gy      WGRAD: gy
+    const float *B;      // FWD: w      DGRAD: w       WGRAD: x
+    float *C;            // FWD: y      DGRAD: gx      WGRAD: gw / split slabs
+    const float *bias, *scale, *shift, *residual;
+    int M, N;            // output tile space (rows, cols)
+    int Kc;              // FWD: C_in   DGRAD: K_out   WGRAD: #pixels
+    int gp, gq;          // pixel grid the rows (FWD/DGRAD) or K index (WGRAD) run over
+    int sh, sw;          // spatial dims of the gathered tensor
+    int R, S, stride, pad;
+    int lda;             // channel stride (floats) of a pixel of the gathered tensor
+    int ldb;             // FWD: row stride of w (R*S*C); DGRAD: R*S*C_in; WGRAD: unused
+    int ldg;             // WGRAD: row stride of gy
+    int cin;             // DGRAD/WGRAD: C_in
+    int ldc;             // output row stride
+    int flags;
+    int out_mode;
+    int oh, ow, ko;      // OUT_STRIDED: gx spatial dims; OUT_DECONV: ko = out channels
+    int stem;            // FWD: stem gather (8 pixels x 4 ch per K slice)
+    int split_len;       // WGRAD: pixels per split
+    int64_t split_stride;// WGRAD: floats between split slabs
+};
+
+template <int TM, int TN, int MODE>
+struct Cfg {
+    static constexpr int BM = 64 * TM, BN = 64 * TN;
+    static constexpr bool A_KC = (MODE != WGRAD);  // A K-contiguous?
+    static constexpr bool B_KC = (MODE == FWD);
+    static constexpr int A_FLOATS = A_KC ? BM * (BK + KPAD) : BK * BM;
+    static constexpr int B_FLOATS = B_KC ? BN * (BK + KPAD) : BK * BN;
+    static constexpr int A_V4 = BM * BK / 4 / 256;  // float4 per thread per slice
+    static constexpr int B_V4 = BN * BK / 4 / 256;
+};
+
+__device__ __forceinline__ float4 ldg4(const float *p, bool ok)
+{
+    return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int TM, int TN, int MODE>
+__global__ void __launch_bounds__(256)
+conv_gemm_kernel(const GemmParams p)
+{
+    using C_ = Cfg<TM, TN, MODE>;
+    constexpr int BM = C_::BM, BN = C_::BN;
+    constexpr int AV = C_::A_V4, BV = C_::B_V4;
+    __shared__ __attribute__((aligned(16))) float smem[2][C_::A_FLOATS + C_::B_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // tile -> (m0, n0); blockIdx.x runs along N fastest so that consecutive
+    // blocks share the gathered A rows.
+    const int ntn = (p.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / ntn) * BM;
+    const int n0 = (blockIdx.x % ntn) * BN;
+
+    // ---------------- per-thread gather state -----------------------------------
+    // K-contiguous operands: thread covers rows (tid/8 + 32*i), float4 column tid%8.
+    // K-strided operands:    thread covers k rows (tid/(BX/4) + ...), float4 column.
+    const int kc_row = tid >> 3, kc_c4 = tid & 7;
+
+    int a_n[AV], a_y[AV], a_x[AV];     // FWD/DGRAD: pixel coords of each A row
+    bool a_ok[AV];
+    if (MODE != WGRAD) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int m = m0 + kc_row + 32 * i;
+            a_ok[i] = m < p.M;
+            const int mm = a_ok[i] ? m : 0;
+            const int n = mm / (p.gp * p.gq);
+            const int rem = mm - n * (p.gp * p.gq);
+            const int gy = rem / p.gq, gx = rem - gy * p.gq;
+            a_n[i] = n;
+            if (MODE == FWD) { a_y[i] = gy * p.stride - p.pad; a_x[i] = gx * p.stride - p.pad; }
+            else { a_y[i] = gy + p.pad; a_x[i] = gx + p.pad; }
+        }
+    }
+    // WGRAD: K-strided tiles.  A' = gy^T: k row = tid/(BM/4), col4 = tid%(BM/4).
+    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;            // threads per k row
+    constexpr int A_RPP = 256 / A_TPR, B_RPP = 256 / B_TPR;  // k rows per pass
+    const int wa_k = tid / A_TPR, wa_c4 = tid % A_TPR;
+    const int wb_k = tid / B_TPR, wb_c4 = tid % B_TPR;
+    // WGRAD B' (im2col(x)^T): the thread's column (r,s,c) is fixed; pixels advance.
+    int wr = 0, ws_ = 0, wc = 0;
+    bool wcol_ok = false;
+    int pn[BV], py[BV], px[BV];
+    int k_begin = 0, k_end = 0;
+    if (MODE == WGRAD) {
+        const int j = n0 + wb_c4 * 4;
+        wcol_ok = j < p.N;
+        const int jj = wcol_ok ? j : 0;
+        const int rs = jj / p.cin;
+        wc = jj - rs * p.cin;
+        wr = rs / p.S;
+        ws_ = rs - wr * p.S;
+        k_begin = blockIdx.y * p.split_len;
+        k_end = min(p.Kc, k_begin + p.split_len);
+#pragma unroll
+        for (int i = 0; i < BV; ++i) {
+            const int m = k_begin + wb_k + B_RPP * i;
+            const int n = m / (p.gp * p.gq);
+            const int rem = m - n * (p.gp * p.gq);
+            pn[i] = n;
+            py[i] = rem / p.gq;
+            px[i] = rem - py[i] * p.gq;
+        }
+    }
+
+    const int cprs = (MODE == WGRAD) ? 1 : (p.Kc + BK - 1) / BK;  // K slices per (r,s)
+    const int nslices = (MODE == WGRAD) ? (k_end - k_begin + BK - 1) / BK : p.R * p.S * cprs;
+
+    float4 ra[AV], rb[BV];
+
+    auto load_slice = [&](int kt) {
+        if (MODE == FWD || MODE == DGRAD) {
+            const int rs = kt / cprs;
+            const int c0 = (kt - rs * cprs) * BK;
+            const int r = rs / p.S, s = rs - r * p.S;
+            const int cc = c0 + kc_c4 * 4;
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                int iy, ix;
+                if (MODE == FWD) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? kc_c4 : 0); }
+                else { iy = a_y[i] - r; ix = a_x[i] - s; }
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.sh &&
+                                (unsigned)ix < (unsigned)p.sw && (p.stem || cc < p.Kc);
+                const int off = ((a_n[i] * p.sh + iy) * p.sw + ix) * p.lda + (p.stem ? 0 : cc);
+                ra[i] = ldg4(p.A + off, ok);
+            }
+            if (MODE == FWD) {
+#pragma unroll
+                for (int i = 0; i < BV; ++i) {
+                    const int n = n0 + kc_row + 32 * i;
+                    const bool ok = n < p.N && cc < p.Kc;
+                    rb[i] = ldg4(p.B + (int64_t)n * p.ldb + rs * p.Kc + cc, ok);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < BV; ++i) {
+                    const int k = c0 + wb_k + B_RPP * i;
+                    const int n = n0 + wb_c4 * 4;
+                    const bool ok = k < p.Kc && n < p.N;
+                    rb[i] = ldg4(p.B + (int64_t)k * p.ldb + rs * p.cin + n, ok);
+                }
+            }
+        } else {
+            const int kb = k_begin + kt * BK;
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                const int m = kb + wa_k + A_RPP * i;
+                const int k = m0 + wa_c4 * 4;
+                ra[i] = ldg4(p.A + (int64_t)m * p.ldg + k, m < k_end && k < p.M);
+            }
+#pragma unroll
+            for (int i = 0; i < BV; ++i) {
+                const int m = kb + wb_k + B_RPP * i;
+                const int iy = py[i] * p.stride - p.pad + wr;
+                const int ix = px[i] * p.stride - p.pad + ws_;
+                const bool ok = wcol_ok && m < k_end && (unsigned)iy < (unsigned)p.sh &&
+                                (unsigned)ix < (unsigned)p.sw;
+                const int off = ((pn[i] * p.sh + iy) * p.sw + ix) * p.lda + wc;
+                rb[i] = ldg4(p.B + off, ok);
+                // advance this row's pixel by BK for the next slice
+                if (p.gp * p.gq == 1) {
+                    pn[i] += BK;
+                } else {
+                    px[i] += BK;
+                    while (px[i] >= p.gq) {
+                        px[i] -= p.gq;
+                        if (++py[i] >= p.gp) { py[i] = 0; ++pn[i]; }
+                    }
+                }
+            }
+        }
+    };
+
+    auto store_slice = [&](int buf) {
+        float *sa = smem[buf];
+        float *sb = smem[buf] + C_::A_FLOATS;
+        if (C_::A_KC) {
+#pragma unroll
+            for (int i = 0; i < AV; ++i)
+                *reinterpret_cast<float4 *>(sa + (kc_row + 32 * i) * (BK + KPAD) + kc_c4 * 4) = ra[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < AV; ++i)
+                *reinterpret_cast<float4 *>(sa + (wa_k + A_RPP * i) * BM + wa_c4 * 4) = ra[i];
+        }
+        if (C_::B_KC) {
+#pragma unroll
+            for (int i = 0; i < BV; ++i)
+                *reinterpret_cast<float4 *>(sb + (kc_row + 32 * i) * (BK + KPAD) + kc_c4 * 4) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < BV; ++i)
+                *reinterpret_cast<float4 *>(sb + (wb_k + B_RPP * i) * BN + wb_c4 * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int li = lane & 31, lk = lane >> 5;
+
+    auto compute = [&](int buf) {
+        const float *sa = smem[buf];
+        const float *sb = smem[buf] + C_::A_FLOATS;
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            float af[TM][4], bf[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (32 * TM) + i * 32 + li;
+                if (C_::A_KC) {
+                    const float4 v = *reinterpret_cast<const float4 *>(
+                        sa + row * (BK + KPAD) + kb * 8 + lk * 4);
+                    af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) af[i][t] = sa[(kb * 8 + lk * 4 + t) * BM + row];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * (32 * TN) + j * 32 + li;
+                if (C_::B_KC) {
+                    const float4 v = *reinterpret_cast<const float4 *>(
+                        sb + col * (BK + KPAD) + kb * 8 + lk * 4);
+                    bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bf[j][t] = sb[(kb * 8 + lk * 4 + t) * BN + col];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t],
+                                                                         acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nslices > 0) {
+        load_slice(0);
+        store_slice(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nslices; ++kt) {
+        const bool more = kt + 1 < nslices;
+        if (more) load_slice(kt + 1);
+        compute(kt & 1);
+        if (more) store_slice((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ------------------------------------------------------
+    float *out = p.C;
+    if (MODE == WGRAD) out += (int64_t)blockIdx.y * p.split_stride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (32 * TN) + j * 32 + li;
+        if (col >= p.N) continue;
+        float bias = 0.f, scale = 1.f, shift = 0.f;
+        if (MODE == FWD || MODE == DGRAD) {
+            if (p.flags & MRCNN_EPI_BIAS) bias = p.bias[p.out_mode == OUT_DECONV ? col % p.ko : col];
+            if (p.flags & MRCNN_EPI_AFFINE) { scale = p.scale[col]; shift = p.shift[col]; }
+        }
+        int64_t col_off = col;
+        if (MODE == DGRAD && p.out_mode == OUT_DECONV) {
+            const int ab = col / p.ko, o = col - ab * p.ko;
+            const int a = ab >> 1, b = ab & 1;
+            col_off = ((int64_t)a * (2 * p.gq) + b) * p.ko + o;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (row >= p.M) continue;
+                int64_t off;
+                if (MODE == DGRAD && p.out_mode == OUT_STRIDED) {
+                    const int n = row / (p.gp * p.gq);
+                    const int rem = row - n * (p.gp * p.gq);
+                    const int gy = rem / p.gq, gx = rem - gy * p.gq;
+                    off = (((int64_t)n * p.oh + gy * p.stride) * p.ow + gx * p.stride) * p.ldc + col_off;
+                } else if (MODE == DGRAD && p.out_mode == OUT_DECONV) {
+                    const int n = row / (p.gp * p.gq);
+                    const int rem = row - n * (p.gp * p.gq);
+                    const int gy = rem / p.gq, gx = rem - gy * p.gq;
+                    off = (((int64_t)n * (2 * p.gp) + 2 * gy) * (2 * p.gq) + 2 * gx) * p.ko + col_off;
+                } else {
+                    off = (int64_t)row * p.ldc + col_off;
+                }
+                float v = acc[i][j][e];
+                if (MODE != WGRAD) {
+                    if (p.flags & MRCNN_EPI_BIAS) v += bias;
+                    if (p.flags & MRCNN_EPI_AFFINE) v = v * scale + shift;
+                    if (p.flags & MRCNN_EPI_RESIDUAL) v += p.residual[off];
+                    if (p.flags & MRCNN_EPI_ACCUM) v += out[off];
+                    if (p.flags & MRCNN_EPI_RELU) v = fmaxf(v, 0.f);
+                }
+                out[off] = v;
+            }
+        }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, int64_t n,
+                                     int64_t stride, float *__restrict__ out)
+{
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4 *>(ws)[i];
+        for (int s = 1; s < splits; ++s) {
+            const float4 v = reinterpret_cast<const float4 *>(ws + s * stride)[i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = a;
+    }
+}
+
+template <int MODE>
+int launch(const GemmParams &p, int splits, hipStream_t s)
+{
+    // 128x128 tiles when they fill the chip at least ~1.5x, else 64x64.
+    const int64_t big = mrcnn::ceil_div(p.M, 128) * mrcnn::ceil_div(p.N, 128) * splits;
+    if (big >= 384 && p.N > 64 && p.M > 64) {
+        const int64_t blocks = mrcnn::ceil_div(p.M, 128) * mrcnn::ceil_div(p.N, 128);
+        hipLaunchKernelGGL((conv_gemm_kernel<2, 2, MODE>), dim3((unsigned)blocks, splits), dim3(256),
+                           0, s, p);
+    } else {
+        const int64_t blocks = mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
+        hipLaunchKernelGGL((conv_gemm_kernel<1, 1, MODE>), dim3((unsigned)blocks, splits), dim3(256),
+                           0, s, p);
+    }
+    return mrcnn::check_launch("conv_gemm");
+}
+
+int check_desc(const mrcnn_conv_desc *d)
+{
+    MRCNN_REQUIRE(d, "conv: null descriptor");
+    MRCNN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 &&
+                      d->stride > 0 && d->pad >= 0,
+                  "conv: bad descriptor");
+    MRCNN_REQUIRE(d->P == (d->H + 2 * d->pad - d->R) / d->stride + 1 &&
+                      d->Q == (d->W + 2 * d->pad - d->S) / d->stride + 1,
+                  "conv: output size (%d,%d) inconsistent with input (%d,%d) k=%d s=%d p=%d", d->P,
+                  d->Q, d->H, d->W, d->R, d->stride, d->pad);
+    MRCNN_REQUIRE(d->C % 4 == 0 && d->K % 4 == 0,
+                  "conv: channel counts must be multiples of 4 (C=%d K=%d)", d->C, d->K);
+    MRCNN_REQUIRE((int64_t)d->N * d->H * d->W * d->C < (int64_t)INT32_MAX &&
+                      (int64_t)d->N * d->P * d->Q * d->K < (int64_t)INT32_MAX,
+                  "conv: tensor exceeds 2^31 elements");
+    return 0;
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p % 16) == 0; }
+
+int wgrad_splits(int64_t tiles, int64_t pixels)
+{
+    // enough workgroups to fill 256 CUs ~3x, each split at least 8 K slices deep
+    int64_t want = mrcnn::ceil_div(768, tiles);
+    int64_t maxs = std::max<int64_t>(1, pixels / (8 * BK));
+    int64_t s = std::max<int64_t>(1, std::min(want, maxs));
+    return (int)std::min<int64_t>(s, 64);
+}
+
+}  // namespace
+
+extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
+                                const float *bias, const float *scale, const float *shift,
+                                const float *residual, float *y, int epi_flags, void *stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    MRCNN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+    MRCNN_REQUIRE(aligned16(x) && aligned16(w), "conv2d_fwd: x/w must be 16-byte aligned");
+    MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_BIAS) || bias, "conv2d_fwd: bias flag without bias");
+    MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_AFFINE) || (scale && shift), "conv2d_fwd: affine flag without scale/shift");
+    MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_RESIDUAL) || residual, "conv2d_fwd: residual flag without residual");
+    GemmParams p = {};
+    p.A = x; p.B = w; p.C = y;
+    p.bias = bias; p.scale = scale; p.shift = shift; p.residual = residual;
+    p.M = d->N * d->P * d->Q; p.N = d->K; p.Kc = d->C;
+    p.gp = d->P; p.gq = d->Q; p.sh = d->H; p.sw = d->W;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
+    p.lda = d->C; p.ldb = d->R * d->S * d->C; p.ldc = d->K;
+    p.flags = epi_flags; p.out_mode = OUT_PLAIN;
+    return launch<FWD>(p, 1, mrcnn::as_stream(stream));
+}
+
+// Stem: conv1 7x7/2 pad 3 of chainer ResNet50Layers on an input
+// padded to 4 channels; filter given as (K, 7, 8, 4) with zeros at s=7 / c=3.
+extern "C" int mrcnn_conv_stem_fwd(const float *x4, const float *w784, const float *bias,
+                                   const float *scale, const float *shift, float *y, int N, int H,
+                                   int W, int K, int epi_flags, void *stream)
+{
+    MRCNN_REQUIRE(x4 && w784 && y, "conv_stem: null pointer");
+    MRCNN_REQUIRE(N > 0 && H > 0 && W > 0 && K > 0 && K % 4 == 0, "conv_stem: bad shape");
+    MRCNN_REQUIRE(aligned16(x4) && aligned16(w784), "conv_stem: pointers must be 16-byte aligned");
+    const int P = (H + 6 - 7) / 2 + 1, Q = (W + 6 - 7) / 2 + 1;
+    GemmParams p = {};
+    p.A = x4; p.B = w784; p.C = y;
+    p.bias = bias; p.scale = scale; p.shift = shift;
+    p.M = N * P * Q; p.N = K; p.Kc = 32;
+    p.gp = P; p.gq = Q; p.sh = H; p.sw = W;
+    p.R = 7; p.S = 1; p.stride = 2; p.pad = 3;
+    p.lda = 4; p.ldb = 7 * 32; p.ldc = K;
+    p.flags = epi_flags; p.out_mode = OUT_PLAIN; p.stem = 1;
+    return launch<FWD>(p, 1, mrcnn::as_stream(stream));
+}
+
+extern "C" int mrcnn_conv2d_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w,
+                                  float *gx, int epi_flags, void *stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    MRCNN_REQUIRE(gy && w && gx, "conv2d_dgrad: null pointer");
+    MRCNN_REQUIRE(aligned16(gy) && aligned16(w), "conv2d_dgrad: gy/w must be 16-byte aligned");
+    MRCNN_REQUIRE((epi_flags & ~MRCNN_EPI_ACCUM) == 0, "conv2d_dgrad: only MRCNN_EPI_ACCUM is valid");
+    hipStream_t s = mrcnn::as_stream(stream);
+    GemmParams p = {};
+    p.A = gy; p.B = w; p.C = gx;
+    p.N = d->C; p.Kc = d->K; p.cin = d->C;
+    p.R = d->R; p.S = d->S; p.pad = d->pad;
+    p.lda = d->K; p.ldb = d->R * d->S * d->C; p.ldc = d->C;
+    p.flags = epi_flags;
+    p.sh = d->P; p.sw = d->Q;
+    if (d->stride == 1) {
+        p.M = d->N * d->H * d->W; p.gp = d->H; p.gq = d->W; p.stride = 1;
+        p.out_mode = OUT_PLAIN;
+    } else {
+        MRCNN_REQUIRE(d->R == 1 && d->S == 1 && d->pad == 0,
+                      "conv2d_dgrad: stride>1 is implemented for 1x1/pad0 (the only strided "
+                      "trainable convs of ResNet-C4) and the 2x2/2 adjoint (deconv entry points)");
+        p.M = d->N * d->P * d->Q; p.gp = d->P; p.gq = d->Q; p.stride = d->stride;
+        p.out_mode = OUT_STRIDED; p.oh = d->H; p.ow = d->W;
+        if (!(epi_flags & MRCNN_EPI_ACCUM))
+            MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)d->N * d->H * d->W * d->C, s));
+    }
+    return launch<DGRAD>(p, 1, s);
+}
+
+extern "C" int64_t mrcnn_conv2d_wgrad_workspace_bytes(const mrcnn_conv_desc *d)
+{
+    if (!d) return 0;
+    const int64_t gwsz = (int64_t)d->K * d->R * d->S * d->C;
+    return 64 * gwsz * 4;  // upper bound: 64 split slabs
+}
+
+static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int Kout, int64_t pixels,
+                      int N_, int H, int W, int C, int P, int Q, int R, int S, int stride, int pad,
+                      void *ws, hipStream_t s)
+{
+    GemmParams p = {};
+    p.A = gy; p.B = x;
+    p.M = Kout; p.N = R * S * C; p.Kc = (int)pixels;
+    p.gp = P; p.gq = Q; p.sh = H; p.sw = W;
+    p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.lda = C; p.ldg = ldg; p.cin = C; p.ldc = R * S * C;
+    const int64_t gwsz = (int64_t)Kout * R * S * C;
+    const int64_t big = mrcnn::ceil_div(p.M, 128) * mrcnn::ceil_div(p.N, 128);
+    const int64_t tiles = (big >= 96 && p.N > 64 && p.M > 64)
+                              ? big
+                              : mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
+    int splits = wgrad_splits(tiles, pixels);
+    if (!ws) splits = 1;
+    p.split_len = (int)(mrcnn::ceil_div(mrcnn::ceil_div(pixels, splits), BK) * BK);
+    splits = (int)mrcnn::ceil_div(pixels, p.split_len);
+    p.split_stride = gwsz;
+    p.C = splits > 1 ? (float *)ws : gw;
+    // tile-size choice must agree with `tiles` above
+    if (big >= 96 && p.N > 64 && p.M > 64) {
+        hipLaunchKernelGGL((conv_gemm_kernel<2, 2, WGRAD>), dim3((unsigned)big, splits), dim3(256), 0,
+                           s, p);
+    } else {
+        hipLaunchKernelGGL((conv_gemm_kernel<1, 1, WGRAD>), dim3((unsigned)tiles, splits), dim3(256),
+                           0, s, p);
+    }
+    if (splits > 1) {
+        int64_t blocks = mrcnn::ceil_div(gwsz / 4, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const float *)ws, splits, gwsz, gwsz, gw);
+    }
+    return mrcnn::check_launch("conv_wgrad");
+}
+
+extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc *d, const float *x, const float *gy,
+                                  float *gw, void *ws, void *stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    MRCNN_REQUIRE(x && gy && gw, "conv2d_wgrad: null pointer");
+    MRCNN_REQUIRE(aligned16(x) && aligned16(gy) && aligned16(gw) && (!ws || aligned16(ws)),
+                  "conv2d_wgrad: pointers must be 16-byte aligned");
+    return wgrad_impl(gy, d->K, x, gw, d->K, (int64_t)d->N * d->P * d->Q, d->N, d->H, d->W, d->C,
+                      d->P, d->Q, d->R, d->S, d->stride, d->pad, ws, mrcnn::as_stream(stream));
+}
+
+// ---- Deconvolution 2x2 stride 2 (= adjoint of a 2x2/2 convolution g: (N,2H,2W,K) -> (N,H,W,C)
+//      with KRSC filter w (C,2,2,K)) -----------------------------------------------------------
+extern "C" int mrcnn_deconv2x2s2_fwd(const float *x, const float *w, const float *bias, float *y,
+                                     int N, int H, int W, int C, int K, int epi_flags,
+                                     void *stream)
+{
+    MRCNN_REQUIRE(x && w && y, "deconv_fwd: null pointer");
+    MRCNN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && C % 4 == 0 && K % 4 == 0,
+                  "deconv_fwd: bad shape");
+    MRCNN_REQUIRE(aligned16(x) && aligned16(w), "deconv_fwd: x/w must be 16-byte aligned");
+    MRCNN_REQUIRE((epi_flags & ~(MRCNN_EPI_BIAS | MRCNN_EPI_RELU)) == 0, "deconv_fwd: bad flags");
+    MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_BIAS) || bias, "deconv_fwd: bias flag without bias");
+    GemmParams p = {};
+    p.A = x; p.B = w; p.C = y; p.bias = bias;
+    p.M = N * H * W; p.N = 4 * K; p.Kc = C; p.cin = 4 * K;
+    p.gp = H; p.gq = W; p.sh = H; p.sw = W;
+    p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+    p.lda = C; p.ldb = 4 * K; p.ldc = K;
+    p.flags = epi_flags; p.out_mode = OUT_DECONV; p.ko = K;
+    return launch<DGRAD>(p, 1, mrcnn::as_stream(stream));
+}
+
+extern "C" int mrcnn_deconv2x2s2_dgrad(const float *gy, const float *w, float *gx, int N, int H,
+                                       int W, int C, int K, void *stream)
+{
+    // gx = conv2x2/2(gy) with KRSC filter w (C,2,2,K)
+    mrcnn_conv_desc d = {N, 2 * H, 2 * W, K, C, 2, 2, 2, 0, H, W};
+    return mrcnn_conv2d_fwd(&d, gy, w, nullptr, nullptr, nullptr, nullptr, gx, 0, stream);
+}
+
+extern "C" int64_t mrcnn_deconv2x2s2_wgrad_workspace_bytes(int N, int H, int W, int C, int K)
+{
+    return 64ll * C * 4 * K * 4;
+}
+
+extern "C" int mrcnn_deconv2x2s2_wgrad(const float *x, const float *gy, float *gw, int N, int H,
+                                       int W, int C, int K, void *ws, void *stream)
+{
+    MRCNN_REQUIRE(x && gy && gw, "deconv_wgrad: null pointer");
+    MRCNN_REQUIRE(aligned16(x) && aligned16(gy) && aligned16(gw) && (!ws || aligned16(ws)),
+                  "deconv_wgrad: pointers must be 16-byte aligned");
+    // gw[c, (a,b,o)] = sum_m x[m, c] * gy[pix(m,a,b), o] : wgrad of the adjoint conv with
+    // "gy" := x and "x" := gy.
+    return wgrad_impl(x, C, gy, gw, C, (int64_t)N * H * W, N, 2 * H, 2 * W, K, H, W, 2, 2, 2, 0, ws,
+                      mrcnn::as_stream(stream));
+}

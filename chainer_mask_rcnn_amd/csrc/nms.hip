@@ -1,0 +1,193 @@
+// Greedy NMS on score-sorted boxes for gfx950 (wave64).
+//
+// Replaces chainercv's `non_maximum_suppression` (un-vendored dependency; call
+// sites /root/reference/chainer_mask_rcnn/models/mask_rcnn.py:193-194 and, via
+// ProposalCreator, models/region_proposal_network.py:135-138; algorithm
+// SURVEY.md Appendix A.3).  The upstream GPU path builds a 64x64-tile bitmask
+// on the device, copies the whole mask to the host and scans it serially in
+// Python.  Here both phases stay on the device:
+//
+//   1. nms_mask_kernel  — one 64-lane wave per (row block, col block) tile of the
+//      upper triangle; lane i owns row box i and emits one uint64 word whose bit
+//      j says IoU(row_i, col_j) >= thresh.  A wave is exactly one mask word wide.
+//   2. nms_scan_kernel  — one workgroup per NMS problem walks the 64-row chunks:
+//      the in-chunk dependency is resolved in scalar registers from the 64
+//      diagonal words (readlane), then all threads OR the kept rows into the
+//      `removed` bit-vector held in LDS (coalesced row reads).
+//
+// IoU uses the CPU path's exact fp32 operation sequence (no FMA:
+// -ffp-contract=off), so keep sets are bit-identical to oracle/nms_ref.c.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ bool iou_ge(const float4 a, const float area_a, const float4 b,
+                                       const float area_b, const float thresh)
+{
+    const float tly = fmaxf(a.x, b.x), tlx = fmaxf(a.y, b.y);
+    const float bry = fminf(a.z, b.z), brx = fminf(a.w, b.w);
+    float inter = (bry - tly) * (brx - tlx);
+    if (!(tly < bry && tlx < brx)) inter = inter * 0.f;
+    const float iou = inter / (area_a + area_b - inter);
+    return iou >= thresh;
+}
+
+// grid (nblk_max, nblk_max, groups), block 64.
+__global__ void __launch_bounds__(64)
+nms_mask_kernel(const float4 *__restrict__ bbox_all, const int32_t *__restrict__ n_dev, int n_max,
+                int nblk_max, float thresh, uint64_t *__restrict__ mask_all)
+{
+    const int cb = blockIdx.x, rb = blockIdx.y, g = blockIdx.z;
+    if (cb < rb) return;
+    const int n = min(n_dev ? n_dev[g] : n_max, n_max);
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    const float4 *__restrict__ bbox = bbox_all + (int64_t)g * n_max;
+    uint64_t *__restrict__ mask = mask_all + (int64_t)g * n_max * nblk_max;
+
+    __shared__ float4 cbox[64];
+    __shared__ float carea[64];
+    const int lane = threadIdx.x;
+    const int cj = cb * 64 + lane;
+    if (cj < n) {
+        const float4 b = bbox[cj];
+        cbox[lane] = b;
+        carea[lane] = (b.z - b.x) * (b.w - b.y);
+    }
+    __syncthreads();
+    const int ri = rb * 64 + lane;
+    if (ri >= n) return;
+    const float4 a = bbox[ri];
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    const int ncol = min(64, n - cb * 64);
+    uint64_t bits = 0;
+    const int j0 = (cb == rb) ? lane + 1 : 0;
+    for (int j = j0; j < ncol; ++j)
+        if (iou_ge(a, area_a, cbox[j], carea[j], thresh)) bits |= 1ull << j;
+    mask[(int64_t)ri * nblk_max + cb] = bits;
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
+{
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readfirstlane64(uint64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// grid (groups), block 256, dynamic LDS = nblk_max * 8 bytes.
+__global__ void __launch_bounds__(256)
+nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict__ n_dev,
+                int n_max, int nblk_max, int limit, int32_t *__restrict__ keep_all,
+                int32_t *__restrict__ n_keep_all)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t removed[];
+    __shared__ uint64_t s_kept;
+    __shared__ int s_count;
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint64_t *__restrict__ mask = mask_all + (int64_t)g * n_max * nblk_max;
+    int32_t *__restrict__ keep = keep_all + (int64_t)g * n_max;
+    const int n = min(n_dev ? n_dev[g] : n_max, n_max);
+    const int nblk = (n + 63) / 64;
+    for (int c = tid; c < nblk; c += blockDim.x) removed[c] = 0;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (tid < 64) {
+            const int row = blk * 64 + tid;
+            const uint64_t diag = row < n ? mask[(int64_t)row * nblk_max + blk] : 0ull;
+            uint64_t rem = readfirstlane64(removed[blk]);
+            const int nrow = n - blk * 64;
+            if (nrow < 64) rem |= ~((1ull << nrow) - 1ull);
+            uint64_t kept = 0;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const uint64_t dj = readlane64(diag, j);
+                if (!((rem >> j) & 1ull)) {
+                    kept |= 1ull << j;
+                    rem |= dj;
+                }
+            }
+            const int cnt = s_count;
+            if (limit > 0) {
+                int room = limit - cnt;
+                while (__popcll(kept) > room) kept &= ~(1ull << (63 - __clzll((long long)kept)));
+            }
+            if ((kept >> tid) & 1ull)
+                keep[cnt + __popcll(kept & ((1ull << tid) - 1ull))] = row;
+            if (tid == 0) {
+                s_kept = kept;
+                s_count = cnt + __popcll(kept);
+            }
+        }
+        __syncthreads();
+        const uint64_t kept = s_kept;
+        const int cnt = s_count;
+        if (limit > 0 && cnt >= limit) break;
+        if (kept) {
+            const uint64_t *__restrict__ rows = mask + (int64_t)blk * 64 * nblk_max;
+            for (int c = blk + 1 + tid; c < nblk; c += blockDim.x) {
+                uint64_t acc = removed[c];
+                uint64_t k = kept;
+                while (k) {
+                    // up to four independent row loads in flight
+                    const int j0 = __ffsll((long long)k) - 1; k &= k - 1;
+                    uint64_t m0 = rows[(int64_t)j0 * nblk_max + c], m1 = 0, m2 = 0, m3 = 0;
+                    if (k) { const int j1 = __ffsll((long long)k) - 1; k &= k - 1; m1 = rows[(int64_t)j1 * nblk_max + c]; }
+                    if (k) { const int j2 = __ffsll((long long)k) - 1; k &= k - 1; m2 = rows[(int64_t)j2 * nblk_max + c]; }
+                    if (k) { const int j3 = __ffsll((long long)k) - 1; k &= k - 1; m3 = rows[(int64_t)j3 * nblk_max + c]; }
+                    acc |= (m0 | m1) | (m2 | m3);
+                }
+                removed[c] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) n_keep_all[g] = s_count;
+}
+
+}  // namespace
+
+extern "C" int64_t mrcnn_nms_workspace_bytes(int n_max, int groups)
+{
+    const int64_t nblk = (n_max + 63) / 64;
+    return (int64_t)groups * n_max * nblk * 8;
+}
+
+extern "C" int mrcnn_nms_sorted_batched(const float *bbox, const int32_t *n_dev, int groups,
+                                        int n_max, float thresh, int limit, int32_t *keep,
+                                        int32_t *n_keep, void *mask_ws, void *stream)
+{
+    MRCNN_REQUIRE(groups >= 0 && n_max >= 0, "nms: bad shape");
+    hipStream_t s = mrcnn::as_stream(stream);
+    if (groups == 0) return 0;
+    MRCNN_REQUIRE(n_keep, "nms: null n_keep");
+    if (n_max == 0) {
+        MRCNN_HIP_TRY(hipMemsetAsync(n_keep, 0, 4 * (size_t)groups, s));
+        return 0;
+    }
+    MRCNN_REQUIRE(bbox && keep && mask_ws, "nms: null pointer");
+    MRCNN_REQUIRE((uintptr_t)bbox % 16 == 0, "nms: bbox must be 16-byte aligned");
+    const int nblk = (n_max + 63) / 64;
+    MRCNN_REQUIRE(nblk * 8 <= 64 * 1024, "nms: n_max too large (%d)", n_max);
+    MRCNN_REQUIRE(nblk <= 65535 && groups <= 65535, "nms: grid too large");
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, groups), dim3(64), 0, s,
+                       (const float4 *)bbox, n_dev, n_max, nblk, thresh, (uint64_t *)mask_ws);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(groups), dim3(256), (size_t)nblk * 8, s,
+                       (const uint64_t *)mask_ws, n_dev, n_max, nblk, limit, keep, n_keep);
+    return mrcnn::check_launch("nms_sorted");
+}
+
+extern "C" int mrcnn_nms_sorted(const float *bbox, const int32_t *n_dev, int n_max, float thresh,
+                                int limit, int32_t *keep, int32_t *n_keep, void *mask_ws,
+                                void *stream)
+{
+    return mrcnn_nms_sorted_batched(bbox, n_dev, 1, n_max, thresh, limit, keep, n_keep, mask_ws,
+                                    stream);
+}

@@ -1,0 +1,194 @@
+// Proposal path for gfx950: loc2bbox + clip, stable descending top-k, row gather.
+//
+// Replaces the host-side NumPy steps of chainercv's ProposalCreator (an
+// un-vendored dependency of the reference; call site
+// /root/reference/chainer_mask_rcnn/models/region_proposal_network.py:135-138,
+// algorithm: SURVEY.md Appendix A.4), which copies loc/score/anchor to the CPU
+// for every image.  Everything here stays on the device; integer results
+// (order, counts) are bit-exact w.r.t. oracle/np_ref.py.
+//
+// Built with -ffp-contract=off: the box arithmetic is the same sequence of
+// separately rounded fp32 operations NumPy performs.
+#include "common.h"
+
+namespace {
+
+__global__ void decode_clip_kernel(const float4 *__restrict__ anchor,
+                                   const float4 *__restrict__ loc, float4 *__restrict__ roi,
+                                   uint8_t *__restrict__ valid, int n, float img_h, float img_w,
+                                   float min_size)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = anchor[i];  // (y1, x1, y2, x2)
+    const float4 l = loc[i];     // (dy, dx, dh, dw)
+    const float h = a.z - a.x, w = a.w - a.y;
+    const float cy = a.x + 0.5f * h, cx = a.y + 0.5f * w;
+    const float ncy = l.x * h + cy, ncx = l.y * w + cx;
+    // exp in double, rounded once to fp32 (matches oracle/np_ref.py loc2bbox)
+    const float nh = (float)exp((double)l.z) * h;
+    const float nw = (float)exp((double)l.w) * w;
+    float4 r;
+    r.x = ncy - 0.5f * nh;
+    r.y = ncx - 0.5f * nw;
+    r.z = ncy + 0.5f * nh;
+    r.w = ncx + 0.5f * nw;
+    r.x = fminf(fmaxf(r.x, 0.f), img_h);
+    r.z = fminf(fmaxf(r.z, 0.f), img_h);
+    r.y = fminf(fmaxf(r.y, 0.f), img_w);
+    r.w = fminf(fmaxf(r.w, 0.f), img_w);
+    roi[i] = r;
+    if (valid) valid[i] = ((r.z - r.x) >= min_size) && ((r.w - r.y) >= min_size);
+}
+
+// Total-order key: larger key = earlier in `argsort(score)[::-1]` with the
+// documented tie rule (equal scores: lower index first).  0 = invalid.
+__device__ __forceinline__ uint64_t make_key(float s, int idx)
+{
+    s = s + 0.f;  // -0 -> +0
+    uint32_t b = __float_as_uint(s);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((uint64_t)b << 32) | (uint32_t)(~(uint32_t)idx);
+}
+
+__global__ void topk_keys_kernel(const float *__restrict__ score,
+                                 const uint8_t *__restrict__ valid, int n,
+                                 uint64_t *__restrict__ keys, int32_t *__restrict__ n_valid)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool v = false;
+    if (i < n) {
+        v = valid ? (valid[i] != 0) : true;
+        keys[i] = v ? make_key(score[i], i) : 0ull;
+    }
+    const unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, (int)__popcll(b));
+}
+
+// rank[i] = #{j : key_j > key_i}; keys are read with wave-uniform (scalar) loads.
+__global__ void __launch_bounds__(256)
+topk_rank_kernel(const uint64_t *__restrict__ keys, int n, int k, int32_t *__restrict__ order,
+                 const int32_t *__restrict__ n_valid, int32_t *__restrict__ n_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = min(k, *n_valid);
+    const uint64_t ki = i < n ? keys[i] : ~0ull;
+    int cnt = 0;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cnt += keys[j + u] > ki;
+    }
+    for (; j < n; ++j) cnt += keys[j] > ki;
+    if (i < n && ki != 0ull && cnt < k) order[cnt] = i;
+}
+
+__global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx,
+                                   const int32_t *__restrict__ n_dev, int n_max, int cols,
+                                   float *__restrict__ dst)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n_max * cols) return;
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    const int n = n_dev ? min(*n_dev, n_max) : n_max;
+    dst[e] = r < n ? src[(int64_t)idx[r] * cols + c] : 0.f;
+}
+
+__global__ void decode_cls_boxes_kernel(const float4 *__restrict__ roi,
+                                        const float *__restrict__ cls_loc, int ld_loc,
+                                        float4 *__restrict__ cls_bbox, int R, int n_class,
+                                        float inv_scale, float4 mean, float4 stdv, float size_h,
+                                        float size_w, int use_div, float scale)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * n_class) return;
+    const int r = e / n_class, l = e % n_class;
+    float4 a = roi[r];
+    // rois[keep] / scale  (models/mask_rcnn.py:220)
+    if (use_div) { a.x = a.x / scale; a.y = a.y / scale; a.z = a.z / scale; a.w = a.w / scale; }
+    else { a.x *= inv_scale; a.y *= inv_scale; a.z *= inv_scale; a.w *= inv_scale; }
+    const float *lp = cls_loc + (int64_t)r * ld_loc + 4 * l;
+    // roi_cls_loc * std + mean (:225-229)
+    const float dy = lp[0] * stdv.x + mean.x, dx = lp[1] * stdv.y + mean.y;
+    const float dh = lp[2] * stdv.z + mean.z, dw = lp[3] * stdv.w + mean.w;
+    const float h = a.z - a.x, w = a.w - a.y;
+    const float cy = a.x + 0.5f * h, cx = a.y + 0.5f * w;
+    const float ncy = dy * h + cy, ncx = dx * w + cx;
+    const float nh = (float)exp((double)dh) * h;
+    const float nw = (float)exp((double)dw) * w;
+    float4 o;
+    o.x = fminf(fmaxf(ncy - 0.5f * nh, 0.f), size_h);
+    o.y = fminf(fmaxf(ncx - 0.5f * nw, 0.f), size_w);
+    o.z = fminf(fmaxf(ncy + 0.5f * nh, 0.f), size_h);
+    o.w = fminf(fmaxf(ncx + 0.5f * nw, 0.f), size_w);
+    cls_bbox[e] = o;
+}
+
+}  // namespace
+
+extern "C" int mrcnn_decode_clip(const float *anchor, const float *loc, float *roi,
+                                 uint8_t *valid, int n, float img_h, float img_w,
+                                 float min_size, void *stream)
+{
+    MRCNN_REQUIRE(n >= 0, "decode_clip: n < 0");
+    if (n == 0) return 0;
+    MRCNN_REQUIRE(anchor && loc && roi, "decode_clip: null pointer");
+    MRCNN_REQUIRE(((uintptr_t)anchor | (uintptr_t)loc | (uintptr_t)roi) % 16 == 0,
+                  "decode_clip: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(decode_clip_kernel, dim3(mrcnn::ceil_div(n, 256)), dim3(256), 0,
+                       mrcnn::as_stream(stream), (const float4 *)anchor, (const float4 *)loc,
+                       (float4 *)roi, valid, n, img_h, img_w, min_size);
+    return mrcnn::check_launch("decode_clip");
+}
+
+extern "C" int64_t mrcnn_topk_workspace_bytes(int n) { return (int64_t)n * 8 + 64; }
+
+extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, int k,
+                               int32_t *order, int32_t *n_out, void *ws, void *stream)
+{
+    MRCNN_REQUIRE(n >= 0 && k >= 0, "topk_desc: bad n/k");
+    MRCNN_REQUIRE(n == 0 || (score && order && n_out && ws), "topk_desc: null pointer");
+    hipStream_t s = mrcnn::as_stream(stream);
+    if (n == 0) {
+        if (n_out) MRCNN_HIP_TRY(hipMemsetAsync(n_out, 0, 4, s));
+        return 0;
+    }
+    int32_t *n_valid = (int32_t *)ws;
+    uint64_t *keys = (uint64_t *)((char *)ws + 64);
+    MRCNN_HIP_TRY(hipMemsetAsync(n_valid, 0, 4, s));
+    const int blocks = (int)mrcnn::ceil_div(n, 256);
+    hipLaunchKernelGGL(topk_keys_kernel, dim3(blocks), dim3(256), 0, s, score, valid, n, keys,
+                       n_valid);
+    hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks), dim3(256), 0, s, keys, n, k, order, n_valid,
+                       n_out);
+    return mrcnn::check_launch("topk_desc");
+}
+
+extern "C" int mrcnn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev,
+                                 int n_max, int cols, float *dst, void *stream)
+{
+    MRCNN_REQUIRE(n_max >= 0 && cols > 0, "gather_rows: bad shape");
+    if (n_max == 0) return 0;
+    MRCNN_REQUIRE(src && idx && dst, "gather_rows: null pointer");
+    const int64_t total = (int64_t)n_max * cols;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(mrcnn::ceil_div(total, 256)), dim3(256), 0,
+                       mrcnn::as_stream(stream), src, idx, n_dev, n_max, cols, dst);
+    return mrcnn::check_launch("gather_rows");
+}
+
+extern "C" int mrcnn_decode_cls_boxes(const float *roi, const float *cls_loc, int ld_loc,
+                                      float *cls_bbox, int R, int n_class, float scale,
+                                      const float *mean4, const float *std4, float size_h,
+                                      float size_w, void *stream)
+{
+    MRCNN_REQUIRE(R >= 0 && n_class > 0, "decode_cls_boxes: bad shape");
+    if (R == 0) return 0;
+    MRCNN_REQUIRE(roi && cls_loc && cls_bbox && mean4 && std4, "decode_cls_boxes: null pointer");
+    const float4 mean = make_float4(mean4[0], mean4[1], mean4[2], mean4[3]);
+    const float4 stdv = make_float4(std4[0], std4[1], std4[2], std4[3]);
+    hipLaunchKernelGGL(decode_cls_boxes_kernel, dim3(mrcnn::ceil_div((int64_t)R * n_class, 256)),
+                       dim3(256), 0, mrcnn::as_stream(stream), (const float4 *)roi, cls_loc, ld_loc,
+                       (float4 *)cls_bbox, R, n_class, 1.f / scale, mean, stdv, size_h, size_w, 1,
+                       scale);
+    return mrcnn::check_launch("decode_cls_boxes");
+}

@@ -1,0 +1,250 @@
+// ROIAlign forward / backward for gfx950, NHWC.
+//
+// Replaces the two CuPy kernel strings of the reference
+// (/root/reference/chainer_mask_rcnn/functions/roi_align_2d.py:171-288 fwd,
+// :395-522 bwd), which run one thread per NCHW output element with
+// uncoalesced 4-tap gathers.  Here one workgroup owns one output bin
+// (roi, ph, pw): all sample geometry is wave-uniform (SGPR) arithmetic derived
+// from blockIdx, and the lanes run across channels, so every tap is a
+// contiguous 16 B/lane read of the NHWC feature row and the result is one
+// contiguous 16 B/lane store.  HBM-bound: the forward writes R*PH*PW*C*4 bytes.
+//
+// Built with -ffp-contract=off and the reference's operation order so that the
+// forward is bit-identical to the fp32 CPU restatement (oracle/roi_align_ref.c).
+#include "common.h"
+
+namespace {
+
+struct RoiGeom {
+    int batch;
+    float start_w, start_h, bin_h, bin_w;
+    int grid_h, grid_w;
+    float count;
+};
+
+// roi_align_2d.py:184-211
+__device__ __forceinline__ RoiGeom roi_geom(const float *__restrict__ roi,
+                                            float spatial_scale, int PH, int PW,
+                                            int sampling_ratio)
+{
+    RoiGeom g;
+    g.batch = (int)roi[0];
+    g.start_w = roi[1] * spatial_scale;
+    g.start_h = roi[2] * spatial_scale;
+    float end_w = roi[3] * spatial_scale;
+    float end_h = roi[4] * spatial_scale;
+    float roi_w = fmaxf(end_w - g.start_w, 1.f);
+    float roi_h = fmaxf(end_h - g.start_h, 1.f);
+    g.bin_h = roi_h / (float)PH;
+    g.bin_w = roi_w / (float)PW;
+    g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_h / (float)PH);
+    g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_w / (float)PW);
+    g.count = (float)(g.grid_h * g.grid_w);
+    return g;
+}
+
+struct Tap1D {
+    int lo, hi;
+    float l, h;  // weight of hi / lo
+    bool valid;
+};
+
+// one axis of roi_align_2d.py:228-262
+__device__ __forceinline__ Tap1D tap1d(float p, int size)
+{
+    Tap1D t;
+    t.valid = !(p < -1.f || p > (float)size);
+    if (p <= 0.f) p = 0.f;
+    int lo = (int)p;
+    int hi;
+    if (lo >= size - 1) {
+        hi = lo = size - 1;
+        p = (float)lo;
+    } else {
+        hi = lo + 1;
+    }
+    t.lo = lo;
+    t.hi = hi;
+    t.l = p - (float)lo;
+    t.h = 1.f - t.l;
+    return t;
+}
+
+template <typename V> struct VecOps;
+template <> struct VecOps<float> {
+    static __device__ __forceinline__ float zero() { return 0.f; }
+    static __device__ __forceinline__ float mad4(float acc, float w1, float v1, float w2, float v2,
+                                                 float w3, float v3, float w4, float v4)
+    {
+        return acc + (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+    }
+    static __device__ __forceinline__ float div(float a, float c) { return a / c; }
+};
+template <> struct VecOps<float4> {
+    static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ float4 mad4(float4 acc, float w1, float4 v1, float w2,
+                                                  float4 v2, float w3, float4 v3, float w4,
+                                                  float4 v4)
+    {
+        acc.x += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x);
+        acc.y += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y);
+        acc.z += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z);
+        acc.w += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
+        return acc;
+    }
+    static __device__ __forceinline__ float4 div(float4 a, float c)
+    {
+        return make_float4(a.x / c, a.y / c, a.z / c, a.w / c);
+    }
+};
+
+// V = float4 when C % 4 == 0 (CV = C/4 vectors per pixel), else float.
+template <typename V>
+__global__ void roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois,
+                                     V *__restrict__ y, int H, int W, int CV, int PH, int PW,
+                                     float spatial_scale, int sampling_ratio)
+{
+    const int bin = blockIdx.x;  // ((n*PH)+ph)*PW+pw
+    const int pw = bin % PW;
+    const int ph = (bin / PW) % PH;
+    const int n = bin / (PW * PH);
+    const RoiGeom g = roi_geom(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio);
+    const V *__restrict__ img = x + (int64_t)g.batch * H * W * CV;
+    V *__restrict__ out = y + (int64_t)bin * CV;
+
+    for (int c = threadIdx.x; c < CV; c += blockDim.x) {
+        V acc = VecOps<V>::zero();
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float yy = g.start_h + ph * g.bin_h +
+                             (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
+            const Tap1D ty = tap1d(yy, H);
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float xx = g.start_w + pw * g.bin_w +
+                                 (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
+                const Tap1D tx = tap1d(xx, W);
+                if (!(ty.valid && tx.valid)) continue;
+                const float w1 = ty.h * tx.h, w2 = ty.h * tx.l;
+                const float w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+                const V v1 = img[((int64_t)ty.lo * W + tx.lo) * CV + c];
+                const V v2 = img[((int64_t)ty.lo * W + tx.hi) * CV + c];
+                const V v3 = img[((int64_t)ty.hi * W + tx.lo) * CV + c];
+                const V v4 = img[((int64_t)ty.hi * W + tx.hi) * CV + c];
+                acc = VecOps<V>::mad4(acc, w1, v1, w2, v2, w3, v3, w4, v4);
+            }
+        }
+        out[c] = VecOps<V>::div(acc, g.count);
+    }
+}
+
+__device__ __forceinline__ void atomic_add_vec(float *p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_vec(float4 *p, float4 v)
+{
+    float *q = reinterpret_cast<float *>(p);
+    unsafeAtomicAdd(q + 0, v.x);
+    unsafeAtomicAdd(q + 1, v.y);
+    unsafeAtomicAdd(q + 2, v.z);
+    unsafeAtomicAdd(q + 3, v.w);
+}
+__device__ __forceinline__ float scale_div(float d, float w, float c) { return d * w / c; }
+__device__ __forceinline__ float4 scale_div(float4 d, float w, float c)
+{
+    return make_float4(d.x * w / c, d.y * w / c, d.z * w / c, d.w * w / c);
+}
+
+// roi_align_2d.py:395-522: g_k = top_diff * w_k / count, scatter-add.
+template <typename V>
+__global__ void roi_align_bwd_kernel(const V *__restrict__ gy, const float *__restrict__ rois,
+                                     V *__restrict__ gx, int H, int W, int CV, int PH, int PW,
+                                     float spatial_scale, int sampling_ratio)
+{
+    const int bin = blockIdx.x;
+    const int pw = bin % PW;
+    const int ph = (bin / PW) % PH;
+    const int n = bin / (PW * PH);
+    const RoiGeom g = roi_geom(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio);
+    V *__restrict__ img = gx + (int64_t)g.batch * H * W * CV;
+    const V *__restrict__ top = gy + (int64_t)bin * CV;
+
+    for (int c = threadIdx.x; c < CV; c += blockDim.x) {
+        const V d = top[c];
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float yy = g.start_h + ph * g.bin_h +
+                             (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
+            const Tap1D ty = tap1d(yy, H);
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float xx = g.start_w + pw * g.bin_w +
+                                 (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
+                const Tap1D tx = tap1d(xx, W);
+                if (!(ty.valid && tx.valid)) continue;
+                const float w1 = ty.h * tx.h, w2 = ty.h * tx.l;
+                const float w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+                atomic_add_vec(&img[((int64_t)ty.lo * W + tx.lo) * CV + c], scale_div(d, w1, g.count));
+                atomic_add_vec(&img[((int64_t)ty.lo * W + tx.hi) * CV + c], scale_div(d, w2, g.count));
+                atomic_add_vec(&img[((int64_t)ty.hi * W + tx.lo) * CV + c], scale_div(d, w3, g.count));
+                atomic_add_vec(&img[((int64_t)ty.hi * W + tx.hi) * CV + c], scale_div(d, w4, g.count));
+            }
+        }
+    }
+}
+
+inline int pick_threads(int cv)
+{
+    int t = ((cv + 63) / 64) * 64;
+    return t > 256 ? 256 : (t < 64 ? 64 : t);
+}
+
+int check_args(const void *a, const void *b, const void *c, int N, int H, int W, int C, int R,
+               int PH, int PW, int sampling_ratio)
+{
+    MRCNN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && R >= 0 && PH > 0 && PW > 0,
+                  "roi_align: bad shape N=%d H=%d W=%d C=%d R=%d PH=%d PW=%d", N, H, W, C, R, PH,
+                  PW);
+    MRCNN_REQUIRE(sampling_ratio >= 0, "roi_align: sampling_ratio must be >= 0");
+    MRCNN_REQUIRE(R == 0 || (a && b && c), "roi_align: null pointer");
+    MRCNN_REQUIRE((int64_t)R * PH * PW < (int64_t)INT32_MAX, "roi_align: too many bins");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mrcnn_roi_align_fwd(const float *x, const float *rois, float *y, int N, int H,
+                                   int W, int C, int R, int PH, int PW, float spatial_scale,
+                                   int sampling_ratio, void *stream)
+{
+    if (int rc = check_args(x, rois, y, N, H, W, C, R, PH, PW, sampling_ratio)) return rc;
+    if (R == 0) return 0;
+    const int bins = R * PH * PW;
+    hipStream_t s = mrcnn::as_stream(stream);
+    if (C % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0)) {
+        const int cv = C / 4;
+        hipLaunchKernelGGL(roi_align_fwd_kernel<float4>, dim3(bins), dim3(pick_threads(cv)), 0, s,
+                           (const float4 *)x, rois, (float4 *)y, H, W, cv, PH, PW, spatial_scale,
+                           sampling_ratio);
+    } else {
+        hipLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3(bins), dim3(pick_threads(C)), 0, s, x,
+                           rois, y, H, W, C, PH, PW, spatial_scale, sampling_ratio);
+    }
+    return mrcnn::check_launch("roi_align_fwd");
+}
+
+extern "C" int mrcnn_roi_align_bwd(const float *gy, const float *rois, float *gx, int N, int H,
+                                   int W, int C, int R, int PH, int PW, float spatial_scale,
+                                   int sampling_ratio, void *stream)
+{
+    if (int rc = check_args(gy, rois, gx, N, H, W, C, R, PH, PW, sampling_ratio)) return rc;
+    hipStream_t s = mrcnn::as_stream(stream);
+    MRCNN_REQUIRE(gx != nullptr, "roi_align_bwd: null gx");
+    MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * H * W * C, s));
+    if (R == 0) return 0;
+    const int bins = R * PH * PW;
+    if (C % 4 == 0 && ((uintptr_t)gx % 16 == 0) && ((uintptr_t)gy % 16 == 0)) {
+        const int cv = C / 4;
+        hipLaunchKernelGGL(roi_align_bwd_kernel<float4>, dim3(bins), dim3(pick_threads(cv)), 0, s,
+                           (const float4 *)gy, rois, (float4 *)gx, H, W, cv, PH, PW, spatial_scale,
+                           sampling_ratio);
+    } else {
+        hipLaunchKernelGGL(roi_align_bwd_kernel<float>, dim3(bins), dim3(pick_threads(C)), 0, s, gy,
+                           rois, gx, H, W, C, PH, PW, spatial_scale, sampling_ratio);
+    }
+    return mrcnn::check_launch("roi_align_bwd");
+}

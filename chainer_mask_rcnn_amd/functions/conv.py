@@ -1,0 +1,224 @@
+"""Convolution / deconvolution / linear ops on the fp32-MFMA implicit-GEMM kernel.
+
+Host-side mirror of chainer's ``L.Convolution2D`` (+ the ``AffineChannel2D``,
+residual add and ReLU that follow it inside chainer's Bottleneck blocks),
+``L.Deconvolution2D(k=2, s=2)`` and ``L.Linear`` as the reference uses them
+(/root/reference/chainer_mask_rcnn/models/region_proposal_network.py:75-80,
+models/mask_rcnn_resnet.py:131-143).  Tensors carry the
+reference's logical shapes — x (N,C,H,W), conv W (out,in,kh,kw), deconv W
+(in,out,kh,kw), linear W (out,in) — stored channels-last, which is exactly the
+NHWC / KRSC layout the HIP kernels consume.
+"""
+import torch
+
+from .. import _lib
+from .._lib import ConvDesc, EPI_BIAS, EPI_AFFINE, EPI_RESIDUAL, EPI_RELU, EPI_ACCUM
+from ._layout import nhwc, empty_nhwc
+
+
+def _direct_grad(p):
+    """A parameter whose ``.grad`` is a preallocated arena view is written in place."""
+    return getattr(p, '_direct_grad', False) and p.grad is not None
+
+
+def conv_out_size(size, k, s, p):
+    return (size + 2 * p - k) // s + 1
+
+
+def make_desc(x_shape, w_shape, stride, pad):
+    N, C, H, W = x_shape
+    K, Cw, R, S = w_shape
+    if Cw != C:
+        raise ValueError('conv: input has %d channels, filter expects %d' % (C, Cw))
+    return ConvDesc(N, H, W, C, K, R, S, stride, pad,
+                    conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad))
+
+
+def _colsum(g2d_ptr, M, C, out, device):
+    ws = _lib.workspace(_lib.load().mrcnn_colsum_workspace_bytes(C), device, 'colsum')
+    _lib.call('mrcnn_colsum', g2d_ptr, _lib.ptr(out), M, C, _lib.ptr(ws), _lib.stream_ptr())
+
+
+def epilogue_bwd(gy, y=None, scale=None):
+    """g = gy * (y > 0) * scale[c] on NHWC tensors (any of y/scale may be None)."""
+    N, C = gy.shape[0], gy.shape[1]
+    M = gy.numel() // C
+    g = torch.empty_like(gy)
+    _lib.call('mrcnn_epilogue_bwd', _lib.ptr(gy), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(g),
+              M, C, _lib.stream_ptr())
+    return g
+
+
+class _Conv2dFn(torch.autograd.Function):
+    """y = relu?( affine?( conv(x, W) + b? ) + residual? )"""
+
+    @staticmethod
+    def forward(ctx, x, W, b, scale, shift, residual, stride, pad, relu):
+        _lib.require_device(x, W)
+        x = nhwc(x)
+        Wc = nhwc(W)
+        d = make_desc(x.shape, W.shape, stride, pad)
+        flags = 0
+        if b is not None:
+            flags |= EPI_BIAS
+        if scale is not None:
+            flags |= EPI_AFFINE
+        if residual is not None:
+            residual = nhwc(residual)
+            flags |= EPI_RESIDUAL
+        if relu:
+            flags |= EPI_RELU
+        y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
+        _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(b),
+                  _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(y), flags,
+                  _lib.stream_ptr())
+        ctx.d = d
+        ctx.relu = relu
+        ctx.has_bias = b is not None
+        ctx.has_res = residual is not None
+        ctx.W_param = W
+        ctx.b_param = b
+        ctx.save_for_backward(x, Wc, scale, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, Wc, scale, y = ctx.saved_tensors
+        d = ctx.d
+        gy = nhwc(gy)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], \
+            ctx.has_bias and ctx.needs_input_grad[2]
+        # through ReLU, then through the affine scale
+        gr = epilogue_bwd(gy, y, None) if ctx.relu else gy
+        g = epilogue_bwd(gr, None, scale) if scale is not None else gr
+        M = d.N * d.P * d.Q
+        gx = gW = gb = None
+        if need_x:
+            gx = empty_nhwc((d.N, d.C, d.H, d.W), gy.device)
+            _lib.call('mrcnn_conv2d_dgrad', ctx_desc(d), _lib.ptr(g), _lib.ptr(Wc), _lib.ptr(gx),
+                      0, _lib.stream_ptr())
+        if need_w:
+            W = ctx.W_param
+            direct = _direct_grad(W)
+            gWt = W.grad if direct else empty_nhwc(tuple(W.shape), gy.device)
+            ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
+                                gy.device, 'wgrad')
+            _lib.call('mrcnn_conv2d_wgrad', ctx_desc(d), _lib.ptr(x), _lib.ptr(g),
+                      _lib.ptr(gWt), _lib.ptr(ws), _lib.stream_ptr())
+            gW = None if direct else gWt
+        if need_b:
+            b = ctx.b_param
+            direct = _direct_grad(b)
+            gbt = b.grad if direct else torch.empty((d.K,), dtype=torch.float32, device=gy.device)
+            _colsum(_lib.ptr(g), M, d.K, gbt, gy.device)
+            gb = None if direct else gbt
+        gres = gr if ctx.has_res and ctx.needs_input_grad[5] else None
+        return gx, gW, gb, None, None, gres, None, None, None
+
+
+def ctx_desc(d):
+    import ctypes
+    return ctypes.byref(d)
+
+
+def conv2d(x, W, b=None, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False):
+    """Fused convolution: ``relu(affine(conv(x,W)+b) + residual)`` with each stage optional.
+
+    ``scale``/``shift`` are the AffineChannel2D ``W``/``b`` (frozen: no gradient is
+    produced for them — the reference computes but never uses it,
+    examples/train_common.py:188-190).
+    """
+    return _Conv2dFn.apply(x, W, b, scale, shift, residual, stride, pad, relu)
+
+
+class _StemFn(torch.autograd.Function):
+    """conv1 7x7/2 pad 3 + bias + affine + ReLU, forward only (frozen stem)."""
+
+    @staticmethod
+    def forward(ctx, x4, w784, b, scale, shift):
+        _lib.require_device(x4, w784)
+        N, H, W_, four = x4.shape
+        assert four == 4 and x4.is_contiguous()
+        K = w784.shape[0]
+        P, Q = conv_out_size(H, 7, 2, 3), conv_out_size(W_, 7, 2, 3)
+        y = empty_nhwc((N, K, P, Q), x4.device)
+        flags = EPI_RELU | (EPI_BIAS if b is not None else 0) | \
+            (EPI_AFFINE if scale is not None else 0)
+        _lib.call('mrcnn_conv_stem_fwd', _lib.ptr(x4), _lib.ptr(w784), _lib.ptr(b),
+                  _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y), N, H, W_, K, flags,
+                  _lib.stream_ptr())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        raise _lib.MrcnnHipError(
+            'the ResNet stem is frozen (unchain_backward at res2, '
+            'models/resnet_extractor.py:86-87): no backward is implemented')
+
+
+def stem_conv(x4, w784, b, scale, shift):
+    return _StemFn.apply(x4, w784, b, scale, shift)
+
+
+class _Deconv2x2Fn(torch.autograd.Function):
+    """L.Deconvolution2D(in, out, 2, stride=2) (+ bias, + ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        _lib.require_device(x, W)
+        x = nhwc(x)
+        Wc = nhwc(W)     # logical (C, K, 2, 2) -> physical (C, 2, 2, K)
+        N, C, H, Wd = x.shape
+        K = W.shape[1]
+        if tuple(W.shape) != (C, K, 2, 2):
+            raise ValueError('deconv: filter must be (in, out, 2, 2), got %s' % (tuple(W.shape),))
+        y = empty_nhwc((N, K, 2 * H, 2 * Wd), x.device)
+        flags = (EPI_BIAS if b is not None else 0) | (EPI_RELU if relu else 0)
+        _lib.call('mrcnn_deconv2x2s2_fwd', _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(b), _lib.ptr(y),
+                  N, H, Wd, C, K, flags, _lib.stream_ptr())
+        ctx.dims = (N, H, Wd, C, K)
+        ctx.relu = relu
+        ctx.W_param, ctx.b_param = W, b
+        ctx.save_for_backward(x, Wc, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, Wc, y = ctx.saved_tensors
+        N, H, Wd, C, K = ctx.dims
+        gy = nhwc(gy)
+        g = epilogue_bwd(gy, y, None) if ctx.relu else gy
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = empty_nhwc((N, C, H, Wd), gy.device)
+            _lib.call('mrcnn_deconv2x2s2_dgrad', _lib.ptr(g), _lib.ptr(Wc), _lib.ptr(gx),
+                      N, H, Wd, C, K, _lib.stream_ptr())
+        if ctx.needs_input_grad[1]:
+            W = ctx.W_param
+            direct = _direct_grad(W)
+            gWt = W.grad if direct else empty_nhwc(tuple(W.shape), gy.device)
+            ws = _lib.workspace(
+                _lib.load().mrcnn_deconv2x2s2_wgrad_workspace_bytes(N, H, Wd, C, K),
+                gy.device, 'wgrad')
+            _lib.call('mrcnn_deconv2x2s2_wgrad', _lib.ptr(x), _lib.ptr(g), _lib.ptr(gWt),
+                      N, H, Wd, C, K, _lib.ptr(ws), _lib.stream_ptr())
+            gW = None if direct else gWt
+        if ctx.b_param is not None and ctx.needs_input_grad[2]:
+            b = ctx.b_param
+            direct = _direct_grad(b)
+            gbt = b.grad if direct else torch.empty((K,), dtype=torch.float32, device=gy.device)
+            _colsum(_lib.ptr(g), N * 4 * H * Wd, K, gbt, gy.device)
+            gb = None if direct else gbt
+        return gx, gW, gb, None
+
+
+def deconv2x2s2(x, W, b=None, relu=False):
+    return _Deconv2x2Fn.apply(x, W, b, relu)
+
+
+def linear(x, W, b=None):
+    """L.Linear: y = x.reshape(N,-1) @ W.T + b, as a 1x1 convolution on (N,C,1,1)."""
+    n = x.shape[0]
+    x4 = x.reshape(n, -1, 1, 1)
+    y = conv2d(x4, W.reshape(W.shape[0], W.shape[1], 1, 1), b)
+    return y.reshape(n, W.shape[0])

@@ -1,0 +1,97 @@
+"""ROIAlign on MI355X — drop-in for the reference's
+``chainer_mask_rcnn.functions.roi_align_2d`` / ``ROIAlign2D``
+(/root/reference/chainer_mask_rcnn/functions/roi_align_2d.py:25-60, :527-560).
+
+Same names, argument meaning and error behaviour; tensors are PyTorch-ROCm
+tensors with the reference's logical NCHW shapes (physically channels-last),
+arithmetic is the hand-written HIP kernel behind ``mrcnn_roi_align_fwd/bwd``.
+"""
+import torch
+
+from .. import _lib
+from ._layout import nhwc, empty_nhwc
+
+
+class _ROIAlign2DFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, rois, outh, outw, spatial_scale, sampling_ratio):
+        _lib.require_device(x, rois)
+        x = nhwc(x)
+        rois = rois.contiguous()
+        N, C, H, W = x.shape
+        R = rois.shape[0]
+        y = empty_nhwc((R, C, outh, outw), x.device)
+        _lib.call('mrcnn_roi_align_fwd', _lib.ptr(x), _lib.ptr(rois), _lib.ptr(y),
+                  N, H, W, C, R, outh, outw, spatial_scale, sampling_ratio,
+                  _lib.stream_ptr())
+        # only rois are retained (roi_align_2d.py:62-63 retain_inputs((1,)))
+        ctx.save_for_backward(rois)
+        ctx.x_shape = (N, C, H, W)
+        ctx.args = (outh, outw, spatial_scale, sampling_ratio)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        rois, = ctx.saved_tensors
+        N, C, H, W = ctx.x_shape
+        outh, outw, spatial_scale, sampling_ratio = ctx.args
+        gy = nhwc(gy)
+        gx = empty_nhwc((N, C, H, W), gy.device)
+        _lib.call('mrcnn_roi_align_bwd', _lib.ptr(gy), _lib.ptr(rois), _lib.ptr(gx),
+                  N, H, W, C, rois.shape[0], outh, outw, spatial_scale,
+                  sampling_ratio, _lib.stream_ptr())
+        # no gradient w.r.t. rois (roi_align_2d.py:389, :524)
+        return gx, None, None, None, None, None
+
+
+class ROIAlign2D(object):
+
+    """ROI align over a set of 2d planes (reference: roi_align_2d.py:25-47)."""
+
+    def __init__(self, outh, outw, spatial_scale, sampling_ratio=0):
+        for arg, value in (('outh', outh), ('outw', outw),
+                           ('sampling_ratio', sampling_ratio)):
+            if not (isinstance(value, int) and not isinstance(value, bool)
+                    and value >= 0):
+                raise TypeError(
+                    '{} must be positive integer: {}, {}'
+                    .format(arg, type(value), value))
+        if isinstance(spatial_scale, int):
+            spatial_scale = float(spatial_scale)
+        elif not isinstance(spatial_scale, float):
+            raise TypeError(
+                'spatial_scale must be float: {}'.format(type(spatial_scale)))
+        self.outh, self.outw = outh, outw
+        self.spatial_scale = spatial_scale
+        self.sampling_ratio = sampling_ratio
+
+    def check_type_forward(self, x, rois):
+        # roi_align_2d.py:49-59
+        if not (x.dtype == torch.float32 and x.dim() == 4 and
+                rois.dtype == torch.float32 and rois.dim() == 2 and
+                rois.shape[1] == 5):
+            raise TypeError(
+                'ROIAlign2D expects x: float32 (N,C,H,W), rois: float32 (R,5); got '
+                '{} {} and {} {}'.format(x.dtype, tuple(x.shape), rois.dtype,
+                                         tuple(rois.shape)))
+
+    def __call__(self, x, rois):
+        self.check_type_forward(x, rois)
+        return _ROIAlign2DFn.apply(x, rois, self.outh, self.outw,
+                                   self.spatial_scale, self.sampling_ratio)
+
+
+def roi_align_2d(x, rois, outh, outw, spatial_scale, sampling_ratio=0, axes='xy'):
+    """Spatial Region of Interest (ROI) align function.
+
+    x: (N, C, H, W) float32; rois: (R, 5) float32 rows
+    ``(batch_index, x_min, y_min, x_max, y_max)`` (``axes='xy'``) or
+    ``(batch_index, y_min, x_min, y_max, x_max)`` (``axes='yx'``).
+    Returns (R, C, outh, outw).  Reference: roi_align_2d.py:527-560.
+    """
+    if axes not in ['xy', 'yx']:
+        raise ValueError('Unsupported axes: {}'.format(axes))
+    if axes == 'yx':
+        rois = rois[:, [0, 2, 1, 4, 3]]
+    return ROIAlign2D(outh, outw, spatial_scale, sampling_ratio)(x, rois)

@@ -1,0 +1,221 @@
+/*
+ * mrcnn_hip.h — C ABI of libmrcnn_hip.so, the MI355X (gfx950) implementation of
+ * the Mask R-CNN ResNet-C4 hot path of wkentaro/chainer-mask-rcnn.
+ *
+ * The reference has no FFI of its own (it is 100 % Python; its device code is
+ * CuPy kernel strings and third-party cuDNN/chainercv calls), so each entry
+ * point below cites the reference interface it replaces (file:line under
+ * /root/reference) and is what a ctypes binding on the reference side would
+ * bind (INTEGRATION.md shows that binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error (never throws,
+ *     never aborts); mrcnn_last_error() returns a message for the calling thread.
+ *   - all tensor pointers are DEVICE pointers owned by the caller (allocated by
+ *     PyTorch-ROCm); the library neither frees nor retains them.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work
+ *     is enqueued asynchronously on it, no implicit device synchronisation.
+ *   - activations are NHWC fp32 ("channels-last": the physical layout of a
+ *     torch channels_last tensor whose logical shape is the reference's NCHW);
+ *     conv filters are KRSC = (out, kh, kw, in) fp32 — the channels_last image
+ *     of chainer's (out, in, kh, kw).
+ *   - boxes are (y_min, x_min, y_max, x_max) fp32 as everywhere in the reference
+ *     model (models/mask_rcnn.py:69); RoI rows for pooling are
+ *     (batch_index, x1, y1, x2, y2) as functions/roi_align_2d.py:540-541.
+ */
+#ifndef MRCNN_HIP_H_
+#define MRCNN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ----------------------------------------------------------- */
+const char *mrcnn_last_error(void);
+int mrcnn_abi_version(void);
+/* Number of compute units / device name of the current device (diagnostics). */
+int mrcnn_device_info(int *n_cu, char *name, int name_len);
+
+/* ---- ROIAlign ---------------------------------------------------------- */
+/* Replaces ROIAlign2D.forward_gpu (functions/roi_align_2d.py:162-290).
+ * x (N,H,W,C) NHWC, rois (R,5) = (batch, x1, y1, x2, y2), y (R,PH,PW,C). */
+int mrcnn_roi_align_fwd(const float *x, const float *rois, float *y,
+                        int N, int H, int W, int C, int R, int PH, int PW,
+                        float spatial_scale, int sampling_ratio, void *stream);
+/* Replaces ROIAlign2D.backward_gpu (functions/roi_align_2d.py:391-524).
+ * gy (R,PH,PW,C) -> gx (N,H,W,C); gx is zero-filled by the call. */
+int mrcnn_roi_align_bwd(const float *gy, const float *rois, float *gx,
+                        int N, int H, int W, int C, int R, int PH, int PW,
+                        float spatial_scale, int sampling_ratio, void *stream);
+
+/* ---- AffineChannel2D ---------------------------------------------------- */
+/* Replaces AffineChannel2DFunction.forward / backward
+ * (functions/affine_channel_2d.py:10-22, :38-56).  x,y (M,C) NHWC rows,
+ * W,b (C).  Inside the model the affine is fused into the conv epilogue
+ * (mrcnn_conv2d_fwd); these stand-alone entry points serve the public
+ * `affine_channel_2d` function. gW/gb may be NULL (skipped). */
+int mrcnn_affine_fwd(const float *x, const float *W, const float *b, float *y,
+                     int64_t M, int C, void *stream);
+int64_t mrcnn_colsum_workspace_bytes(int C);
+int mrcnn_affine_bwd(const float *x, const float *W, const float *gy,
+                     float *gx, float *gW, float *gb, int64_t M, int C,
+                     void *ws /* mrcnn_colsum_workspace_bytes(C) */, void *stream);
+
+/* ---- Proposal path (integer results) ------------------------------------ */
+/* loc2bbox + clip + min-size validity: chainercv ProposalCreator steps 1-3
+ * (call site models/region_proposal_network.py:135-138).
+ * anchor (n,4), loc (n,4) -> roi (n,4); valid[i] = h>=min_size && w>=min_size. */
+int mrcnn_decode_clip(const float *anchor, const float *loc, float *roi,
+                      uint8_t *valid, int n, float img_h, float img_w,
+                      float min_size, void *stream);
+/* Stable descending top-k over valid entries: `argsort(score)[::-1][:k]` of
+ * ProposalCreator (tie rule: lower index first).  order[j] = index of the j-th
+ * best valid score (j < *n_out), n_out (device int32) = min(k, #valid).
+ * valid may be NULL (all valid). */
+int64_t mrcnn_topk_workspace_bytes(int n);
+int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, int k,
+                    int32_t *order, int32_t *n_out, void *ws, void *stream);
+/* dst[j,:] = src[idx[j],:] for j < *n_dev (n_dev device int32, rows of `cols`
+ * fp32); rows j >= *n_dev up to n_max are zero-filled. */
+int mrcnn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev,
+                      int n_max, int cols, float *dst, void *stream);
+/* chainercv non_maximum_suppression on score-sorted boxes (call
+ * sites models/mask_rcnn.py:193-194 and ProposalCreator).  bbox (n_max,4)
+ * sorted by descending score, *n_dev boxes valid.  Writes keep[0..*n_keep) =
+ * indices into bbox (ascending = descending score), at most `limit` (<=0: no
+ * limit).  mask_ws: caller-owned workspace of mrcnn_nms_workspace_bytes(n_max, 1). */
+int64_t mrcnn_nms_workspace_bytes(int n_max, int groups);
+int mrcnn_nms_sorted(const float *bbox, const int32_t *n_dev, int n_max,
+                     float thresh, int limit, int32_t *keep, int32_t *n_keep,
+                     void *mask_ws, void *stream);
+/* Batched form for per-class NMS (MaskRCNN._suppress, models/mask_rcnn.py:178-202):
+ * `groups` independent problems, group g has n_dev[g] boxes at bbox + g*n_max*4,
+ * writes keep + g*n_max and n_keep[g]; workspace mrcnn_nms_workspace_bytes(n_max, groups). */
+int mrcnn_nms_sorted_batched(const float *bbox, const int32_t *n_dev, int groups,
+                             int n_max, float thresh, int limit, int32_t *keep,
+                             int32_t *n_keep, void *mask_ws, void *stream);
+
+/* ---- Convolution family (fp32 implicit GEMM on MFMA) ---------------------- */
+/* Epilogue flags */
+#define MRCNN_EPI_BIAS     1   /* y += bias[c]                                  */
+#define MRCNN_EPI_AFFINE   2   /* y = y*scale[c] + shift[c]  (AffineChannel2D)  */
+#define MRCNN_EPI_RESIDUAL 4   /* y += residual[m,c]                            */
+#define MRCNN_EPI_RELU     8   /* y = max(y,0)                                  */
+#define MRCNN_EPI_ACCUM    16  /* y += previous contents of y (dgrad fan-in)    */
+
+typedef struct {
+    int N, H, W, C;        /* input  (N,H,W,C)  NHWC                         */
+    int K, R, S;           /* filter (K,R,S,C)  KRSC                         */
+    int stride, pad;
+    int P, Q;              /* output (N,P,Q,K)  NHWC                         */
+} mrcnn_conv_desc;
+
+/* Replaces chainer L.Convolution2D forward (cuDNN) + following AffineChannel2D,
+ * residual add and ReLU of chainer's BottleneckA/B (call sites
+ * models/region_proposal_network.py:75-80,124-131, models/mask_rcnn_resnet.py:131-143,
+ * chainer ResNet50Layers via models/resnet_extractor.py:93).
+ * y = epi( conv(x, w) ).  scale/shift/bias/residual may be NULL when unused. */
+int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
+                     const float *bias, const float *scale, const float *shift,
+                     const float *residual, float *y, int epi_flags, void *stream);
+/* Gradient w.r.t. the input.  gy (N,P,Q,K) -> gx (N,H,W,C).  With
+ * MRCNN_EPI_ACCUM gx += result (fan-in of several consumers). */
+int mrcnn_conv2d_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w,
+                       float *gx, int epi_flags, void *stream);
+/* Gradient w.r.t. the filter, gw (K,R,S,C) (bias gradient: mrcnn_colsum of gy).
+ * ws: split-K workspace of mrcnn_conv2d_wgrad_workspace_bytes(d) (NULL: no split). */
+int64_t mrcnn_conv2d_wgrad_workspace_bytes(const mrcnn_conv_desc *d);
+int mrcnn_conv2d_wgrad(const mrcnn_conv_desc *d, const float *x, const float *gy,
+                       float *gw, void *ws, void *stream);
+/* Stem: conv1 7x7/2 pad 3 with bias of chainer ResNet50Layers (SURVEY.md A.1;
+ * models/resnet_extractor.py:65-67) fused with bn1-as-affine and ReLU.  x4 is
+ * the image padded to 4 channels (N,H,W,4); w784 is the filter laid out
+ * (K,7,8,4) with zeros at s=7 and c=3.  Forward only (frozen, :86-87). */
+int mrcnn_conv_stem_fwd(const float *x4, const float *w784, const float *bias,
+                        const float *scale, const float *shift, float *y, int N,
+                        int H, int W, int K, int epi_flags, void *stream);
+
+/* Replaces chainer L.Deconvolution2D(2048,256,2,stride=2) (models/mask_rcnn_resnet.py:138-139,193).
+ * x (N,H,W,C) -> y (N,2H,2W,K); filter w (C,2,2,K) = channels_last image of
+ * chainer's (in,out,kh,kw).  Epilogue: bias + optional ReLU. */
+int mrcnn_deconv2x2s2_fwd(const float *x, const float *w, const float *bias,
+                          float *y, int N, int H, int W, int C, int K,
+                          int epi_flags, void *stream);
+int mrcnn_deconv2x2s2_dgrad(const float *gy, const float *w, float *gx,
+                            int N, int H, int W, int C, int K, void *stream);
+int64_t mrcnn_deconv2x2s2_wgrad_workspace_bytes(int N, int H, int W, int C, int K);
+int mrcnn_deconv2x2s2_wgrad(const float *x, const float *gy, float *gw,
+                            int N, int H, int W, int C, int K, void *ws,
+                            void *stream);
+
+/* ReLU / affine backward helper: g[m,c] = gy[m,c] * (y[m,c] > 0) * scale[c]
+ * (scale NULL = 1; y NULL = no mask).  Backward of the fused conv epilogue. */
+int mrcnn_epilogue_bwd(const float *gy, const float *y, const float *scale,
+                       float *g, int64_t M, int C, void *stream);
+/* Column sums: out[c] = sum_m g[m,c] (bias gradients); ws of
+ * mrcnn_colsum_workspace_bytes(C). Deterministic (two-level fixed-order sum). */
+int mrcnn_colsum(const float *g, float *out, int64_t M, int C, void *ws, void *stream);
+
+/* ---- Pooling ------------------------------------------------------------ */
+/* F.max_pooling_2d(x,3,stride=2,pad=1), cover_all=True (models/resnet_extractor.py:69).
+ * x (N,H,W,C) -> y (N,P,Q,C), P = (H+2-3+1)/2+1. Forward only: the stem is
+ * frozen (unchain_backward at res2, models/resnet_extractor.py:86-87). */
+int mrcnn_maxpool3x3s2p1_fwd(const float *x, float *y, int N, int H, int W, int C,
+                             int P, int Q, void *stream);
+/* F.average_pooling_2d(res5, 7, stride=7) on a 7x7 map (models/mask_rcnn_resnet.py:188):
+ * x (R,HW,C) -> y (R,C) mean over HW; backward broadcasts gy/HW. */
+int mrcnn_avgpool_fwd(const float *x, float *y, int R, int HW, int C, void *stream);
+int mrcnn_avgpool_bwd(const float *gy, float *gx, int R, int HW, int C,
+                      int accumulate, void *stream);
+
+/* ---- Losses (models/mask_rcnn_train_chain.py:163-181,192-213) -------------- */
+/* All loss kernels write loss[0] (device scalar, already normalised) and, when gx
+ * is non-NULL, the gradient of that scalar w.r.t. x (the total loss is a plain
+ * sum, :180).  ws: workspace of mrcnn_loss_workspace_bytes(rows) bytes, rows = R
+ * for softmax_ce, 0 otherwise.  No host synchronisation. */
+int64_t mrcnn_loss_workspace_bytes(int rows);
+/* F.sigmoid_cross_entropy(x, t), t in {-1,0,1}; x element i at x[i*x_stride + x_off(i)]:
+ * plain form: x (n) contiguous. */
+int mrcnn_sigmoid_ce(const float *x, const int32_t *t, int64_t n, float *loss,
+                     float *gx, void *ws, void *stream);
+/* mask form: x (R, Kc, HW) NHWC rows = (R, HW, Kc); selects channel label[r]-1
+ * for row r (models/mask_rcnn_train_chain.py:176-178); t (R,HW) in {-1,0,1};
+ * gx (R,HW,Kc) fully written (zeros elsewhere). */
+int mrcnn_mask_sigmoid_ce(const float *x, const int32_t *label, const int32_t *t,
+                          int R, int HW, int Kc, float *loss, float *gx,
+                          void *ws, void *stream);
+/* F.softmax_cross_entropy(x (R,ncls) with row stride ldx, t) ignore -1. */
+int mrcnn_softmax_ce(const float *x, int ldx, const int32_t *t, int R, int ncls,
+                     float *loss, float *gx, int ldg, void *ws, void *stream);
+/* _fast_rcnn_loc_loss: pred (n,4) [row r at pred + r*ld + 4*cls[r] when cls != NULL],
+ * gt_loc (n,4), gt_label (n); in_weight = label>0; normaliser = #(label>=0).
+ * gx written with the same addressing (caller zero-fills the rest). */
+int mrcnn_smooth_l1(const float *pred, int ld, const int32_t *cls,
+                    const float *gt_loc, const int32_t *gt_label, int n,
+                    float sigma, float *loss, float *gx, void *ws, void *stream);
+/* F.softmax(x) row-wise (models/mask_rcnn.py:208) */
+int mrcnn_softmax(const float *x, int ldx, float *y, int ldy, int R, int ncls,
+                  void *stream);
+
+/* ---- Optimizer (chainer MomentumSGD + WeightDecay, examples/train_common.py:176-180) */
+/* g += wd*p; v = momentum*v - lr*g; p += v, over one flat arena of n floats.
+ * grad_scale multiplies g first (1/world_size after an all-reduce sum). */
+int mrcnn_sgd_momentum_wd(float *p, const float *g, float *v, int64_t n, float lr,
+                          float momentum, float wd, float grad_scale,
+                          void *stream);
+
+/* ---- Inference post-processing (models/mask_rcnn.py:204-265) ---------------- */
+/* Per-class decode: cls_bbox[r,l,:] = clip(loc2bbox(roi[r]/scale,
+ * cls_loc[r,l,:]*std+mean), 0, size) for all classes (:225-240). */
+/* mean4/std4 are HOST pointers to 4 floats (loc_normalize_mean/std). */
+int mrcnn_decode_cls_boxes(const float *roi, const float *cls_loc, int ld_loc,
+                           float *cls_bbox, int R, int n_class, float scale,
+                           const float *mean4, const float *std4, float size_h,
+                           float size_w, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRCNN_HIP_H_ */

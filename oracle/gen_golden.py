@@ -1,0 +1,134 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own code.
+
+Runs only in the build container (needs /root/reference).  The reference's
+`chainer_mask_rcnn/functions/roi_align_2d.py` and `affine_channel_2d.py` are
+loaded with importlib under a stand-in `chainer` namespace (chainer itself is
+not installable here; recipe: SURVEY.md Appendix D) and their CPU methods are
+called directly.  Only inputs and outputs (data) are stored.
+
+    python oracle/gen_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference/chainer_mask_rcnn/functions'
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+
+
+def _load_reference():
+    chainer = types.ModuleType('chainer')
+    cuda = types.ModuleType('chainer.cuda')
+    cuda.cupy = None
+    cuda.elementwise = lambda *a, **k: None
+    cuda.get_array_module = lambda *a: np
+    function = types.ModuleType('chainer.function')
+
+    class Function(object):
+        def retain_inputs(self, idx):
+            pass
+    function.Function = Function
+    chainer.Function = Function
+    utils = types.ModuleType('chainer.utils')
+    type_check = types.ModuleType('chainer.utils.type_check')
+    utils.type_check = type_check
+    functions = types.ModuleType('chainer.functions')
+    chainer.cuda, chainer.function, chainer.utils = cuda, function, utils
+    chainer.functions = functions
+    for name, m in [('chainer', chainer), ('chainer.cuda', cuda),
+                    ('chainer.function', function), ('chainer.utils', utils),
+                    ('chainer.utils.type_check', type_check),
+                    ('chainer.functions', functions)]:
+        sys.modules[name] = m
+    mods = {}
+    for fn in ['roi_align_2d', 'affine_channel_2d']:
+        spec = importlib.util.spec_from_file_location(
+            'ref_' + fn, os.path.join(REF, fn + '.py'))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods[fn] = m
+    return mods
+
+
+def _run_roi_align(mod, x, rois_xy, outh, outw, scale, sr, gy):
+    f = mod.ROIAlign2D(outh, outw, scale, sr)
+    y, = f.forward_cpu((x, rois_xy))
+    gx, _ = f.backward_cpu((x, rois_xy), (gy,))
+    return y, gx
+
+
+def main():
+    mods = _load_reference()
+    ra = mods['roi_align_2d']
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.RandomState(1234)
+
+    # (1) geometry of the reference's own unit test
+    #     (tests/functions_tests/test_roi_align_2d.py:20-40) with random x.
+    x = rng.uniform(-1, 1, (3, 3, 12, 8)).astype(np.float32)
+    rois = np.array([[0, 1, 1, 6, 6], [2, 6, 2, 7, 11],
+                     [1, 3, 1, 5, 10], [0, 3, 3, 3, 3]], np.float32)
+    gy = rng.uniform(-1, 1, (4, 3, 5, 7)).astype(np.float32)
+    for sr in (0, 1, 2):
+        y, gx = _run_roi_align(ra, x, rois, 5, 7, 0.6, sr, gy)
+        np.savez(os.path.join(OUT, 'roi_align_testgeom_sr%d.npz' % sr),
+                 x=x, rois=rois, gy=gy, y=y, gx=gx, outh=5, outw=7,
+                 spatial_scale=0.6, sampling_ratio=sr)
+
+    # (2) the 8x8 toy map of tests/functions_tests/check_roi_align_2d.py:24-47
+    toy = rng.uniform(0, 1, (1, 1, 8, 8)).astype(np.float32)
+    for k, r in enumerate([[0, 0, 0, 2, 2], [0, 0, 0, 3, 2], [0, 0, 2, 6, 7]]):
+        rois_k = np.array([r], np.float32)
+        gy_k = np.ones((1, 1, 2, 2), np.float32)
+        y, gx = _run_roi_align(ra, toy, rois_k, 2, 2, 1.0, 0, gy_k)
+        np.savez(os.path.join(OUT, 'roi_align_toy%d.npz' % k),
+                 x=toy, rois=rois_k, gy=gy_k, y=y, gx=gx, outh=2, outw=2,
+                 spatial_scale=1.0, sampling_ratio=0)
+
+    # (3) a C4-like case: N=2, C=8, 51x84 map, 32 proposals clipped to the
+    #     800x1333 image (incl. sub-pixel and full-image boxes), 14x14,
+    #     scale 1/16, adaptive sampling, boxes given yx (axes='yx' path of
+    #     roi_align_2d :557-558; column swap applied here as the wrapper does).
+    N, C, H, W = 2, 8, 51, 84
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    img_h, img_w = 800., 1333.
+    R = 32
+    cy = rng.uniform(0, img_h, R)
+    cx = rng.uniform(0, img_w, R)
+    hh = np.exp(rng.uniform(np.log(4), np.log(800), R))
+    ww = np.exp(rng.uniform(np.log(4), np.log(1333), R))
+    b = np.stack([cy - hh / 2, cx - ww / 2, cy + hh / 2, cx + ww / 2], 1)
+    b[:, 0::2] = np.clip(b[:, 0::2], 0, img_h)
+    b[:, 1::2] = np.clip(b[:, 1::2], 0, img_w)
+    b[0] = [0, 0, img_h, img_w]            # full image
+    b[1] = [100.2, 200.7, 100.9, 201.1]    # sub-pixel
+    b[2] = [790, 1300, 800, 1333]          # bottom-right corner
+    idx = rng.randint(0, N, R).astype(np.float32)
+    rois_yx = np.concatenate([idx[:, None], b], 1).astype(np.float32)
+    rois_xy = rois_yx[:, [0, 2, 1, 4, 3]]
+    gy = rng.standard_normal((R, C, 14, 14)).astype(np.float32)
+    y, gx = _run_roi_align(ra, x, np.ascontiguousarray(rois_xy), 14, 14,
+                           1. / 16, 0, gy)
+    np.savez_compressed(os.path.join(OUT, 'roi_align_c4like.npz'),
+                        x=x, rois_yx=rois_yx, gy=gy, y=y, gx=gx, outh=14,
+                        outw=14, spatial_scale=1. / 16, sampling_ratio=0)
+
+    # (4) AffineChannel2D on the shapes of tests/functions_tests/test_affine_channel_2d.py:17-31
+    af = mods['affine_channel_2d']
+    x = rng.uniform(-1, 1, (3, 3, 12, 8)).astype(np.float32)
+    Wt = rng.random_sample((1, 3, 1, 1)).astype(np.float32)
+    bt = rng.random_sample((1, 3, 1, 1)).astype(np.float32)
+    gy = rng.uniform(-1, 1, x.shape).astype(np.float32)
+    fn = af.AffineChannel2DFunction()
+    y, = fn.forward((x, Wt, bt))
+    gx, gW, gb = fn.backward((x, Wt, bt), (gy,))
+    np.savez(os.path.join(OUT, 'affine_channel_2d.npz'),
+             x=x, W=Wt, b=bt, gy=gy, y=y, gx=gx, gW=gW, gb=gb)
+    print('golden vectors written to', os.path.normpath(OUT))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,94 @@
+"""The C-ABI library builds for gfx950, loads, and exports every symbol that
+include/mrcnn_hip.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'mrcnn_hip.h')
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from chainer_mask_rcnn_amd import _lib
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mrcnn_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_the_path():
+    syms = _declared_symbols()
+    for must in ['mrcnn_roi_align_fwd', 'mrcnn_roi_align_bwd', 'mrcnn_nms_sorted',
+                 'mrcnn_conv2d_fwd', 'mrcnn_conv2d_dgrad', 'mrcnn_conv2d_wgrad',
+                 'mrcnn_deconv2x2s2_fwd', 'mrcnn_sgd_momentum_wd']:
+        assert must in syms
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for s in _declared_symbols():
+        assert hasattr(lib, s), 'libmrcnn_hip.so does not export %s' % s
+
+
+def test_binding_table_covers_header(lib):
+    from chainer_mask_rcnn_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared_symbols()
+
+
+def test_abi_version_and_error_string(lib):
+    assert lib.mrcnn_abi_version() == 1
+    assert isinstance(lib.mrcnn_last_error(), bytes)
+
+
+def test_argument_validation_without_device(lib):
+    # pure host-side checks return an error code and a message, never crash
+    rc = lib.mrcnn_roi_align_fwd(None, None, None, 1, 4, 4, 4, 1, 2, 2,
+                                 ctypes.c_float(1.0), -1, None)
+    assert rc != 0 and b'sampling_ratio' in lib.mrcnn_last_error()
+    from chainer_mask_rcnn_amd._lib import ConvDesc
+    d = ConvDesc(1, 8, 8, 6, 8, 3, 3, 1, 1, 8, 8)   # C=6 not a multiple of 4
+    rc = lib.mrcnn_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
+    assert rc != 0 and b'multiples of 4' in lib.mrcnn_last_error()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'chainer_mask_rcnn_amd')
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith('.py'):
+                src = open(os.path.join(dp, fn)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, fn
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    import torch
+    from chainer_mask_rcnn_amd import functions
+    from chainer_mask_rcnn_amd._lib import MrcnnHipError
+    x = torch.zeros(1, 4, 4, 4)
+    rois = torch.tensor([[0., 0., 0., 2., 2.]])
+    with pytest.raises(MrcnnHipError):
+        functions.roi_align_2d(x, rois, 2, 2, 1.0)
+
+
+def test_roi_align_argument_errors():
+    # error conventions of roi_align_2d.py:30-43, :555-556
+    import torch
+    from chainer_mask_rcnn_amd import functions
+    with pytest.raises(TypeError):
+        functions.ROIAlign2D(2.0, 2, 1.0)
+    with pytest.raises(TypeError):
+        functions.ROIAlign2D(2, 2, 1.0, sampling_ratio=-1)
+    with pytest.raises(TypeError):
+        functions.ROIAlign2D(2, 2, 'a')
+    assert functions.ROIAlign2D(2, 2, 1).spatial_scale == 1.0
+    with pytest.raises(ValueError):
+        functions.roi_align_2d(torch.zeros(1, 1, 2, 2), torch.zeros(1, 5), 2, 2, 1.0, axes='zz')
+    with pytest.raises(TypeError):
+        functions.ROIAlign2D(2, 2, 1.0)(torch.zeros(1, 1, 2, 2), torch.zeros(1, 4))

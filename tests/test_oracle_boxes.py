@@ -1,0 +1,123 @@
+"""Known-answer tests pinning the NumPy/C restatements of the chainercv box
+utilities (no reference golden vectors exist for them: "parity unpinned")."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import np_ref
+
+
+def _rand_boxes(rng, n, size=800.):
+    cy, cx = rng.uniform(0, size, n), rng.uniform(0, size, n)
+    h, w = rng.uniform(4, 300, n), rng.uniform(4, 300, n)
+    b = np.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], 1)
+    return np.clip(b, 0, size).astype(np.float32)
+
+
+def _iou_def(a, b):
+    ih = max(0., min(a[2], b[2]) - max(a[0], b[0]))
+    iw = max(0., min(a[3], b[3]) - max(a[1], b[1]))
+    inter = ih * iw
+    ua = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter
+    return inter / ua if ua > 0 else 0.
+
+
+def _nms_brute(bbox, thresh):
+    keep = []
+    for i in range(len(bbox)):
+        if all(_iou_def(bbox[i].astype(np.float64), bbox[k].astype(np.float64)) < thresh
+               for k in keep):
+            keep.append(i)
+    return np.array(keep, np.int32)
+
+
+def test_bbox_iou_matches_definition():
+    rng = np.random.RandomState(0)
+    a, b = _rand_boxes(rng, 40), _rand_boxes(rng, 30)
+    iou = np_ref.bbox_iou(a, b)
+    ref = np.array([[_iou_def(x, y) for y in b] for x in a])
+    np.testing.assert_allclose(iou, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_loc2bbox_bbox2loc_roundtrip():
+    rng = np.random.RandomState(1)
+    src, dst = _rand_boxes(rng, 50), _rand_boxes(rng, 50)
+    loc = np_ref.bbox2loc(src, dst)
+    back = np_ref.loc2bbox(src, loc)
+    np.testing.assert_allclose(back, dst, rtol=1e-4, atol=1e-2)
+
+
+def test_anchor_base_coco():
+    ab = np_ref.generate_anchor_base(16, (0.5, 1, 2), (2, 4, 8, 16, 32))
+    assert ab.shape == (15, 4) and ab.dtype == np.float32
+    # ratio 1, scale 8 -> 128x128 centred on (8, 8)
+    np.testing.assert_allclose(ab[1 * 5 + 2], [8 - 64, 8 - 64, 8 + 64, 8 + 64])
+    anchors = np_ref.enumerate_shifted_anchor(ab, 16, 51, 84)
+    assert anchors.shape == (64260, 4)
+    np.testing.assert_allclose(anchors[15 + 7] - anchors[7], [0, 16, 0, 16])
+
+
+@pytest.mark.parametrize('thresh', [0.3, 0.5, 0.7])
+def test_nms_numpy_c_and_bruteforce_agree(thresh):
+    rng = np.random.RandomState(2)
+    bbox = _rand_boxes(rng, 400)
+    k_np = np_ref.non_maximum_suppression(bbox, thresh)
+    k_c = oracle.nms_sorted(bbox, thresh)
+    k_bf = _nms_brute(bbox, thresh)
+    assert (k_np == k_c).all()
+    assert (k_np == k_bf).all()
+
+
+def test_nms_with_score_and_limit():
+    rng = np.random.RandomState(3)
+    bbox = _rand_boxes(rng, 200)
+    score = rng.permutation(200).astype(np.float32)
+    k = np_ref.non_maximum_suppression(bbox, 0.5, score=score, limit=7)
+    assert len(k) == 7 and k.dtype == np.int32
+    assert (np.diff(score[k]) < 0).all()
+    assert len(np_ref.non_maximum_suppression(np.zeros((0, 4), np.float32), 0.5)) == 0
+
+
+def test_nms_degenerate_boxes():
+    # zero-area boxes give iou = 0/0 = NaN -> never suppress (A.3)
+    bbox = np.array([[5, 5, 5, 5], [5, 5, 5, 5], [0, 0, 10, 10], [0, 0, 10, 10]], np.float32)
+    assert list(np_ref.non_maximum_suppression(bbox, 0.5)) == [0, 1, 2]
+    assert list(oracle.nms_sorted(bbox, 0.5)) == [0, 1, 2]
+
+
+def test_proposal_creator_counts_and_order():
+    rng = np.random.RandomState(4)
+    ab = np_ref.generate_anchor_base(16, (0.5, 1, 2), (2, 4, 8, 16, 32))
+    anchor = np_ref.enumerate_shifted_anchor(ab, 16, 12, 20)
+    loc = (rng.standard_normal((len(anchor), 4)) * 0.1).astype(np.float32)
+    score = rng.standard_normal(len(anchor)).astype(np.float32)
+    pc = np_ref.ProposalCreator(min_size=0, n_train_pre_nms=600, n_train_post_nms=50,
+                                n_test_pre_nms=300, n_test_post_nms=20)
+    roi, idx = pc(loc, score, anchor, (192, 320), 1., train=True, return_indices=True)
+    assert roi.shape[0] <= 50 and roi.shape[1] == 4
+    assert (np.diff(score[idx]) <= 0).all()
+    assert roi[:, 0::2].min() >= 0 and roi[:, 0::2].max() <= 192
+    roi_t = pc(loc, score, anchor, (192, 320), 1., train=False)
+    assert roi_t.shape[0] <= 20
+
+
+def test_anchor_target_creator_properties():
+    rng = np.random.RandomState(5)
+    np.random.seed(0)
+    ab = np_ref.generate_anchor_base(16, (0.5, 1, 2), (2, 4, 8, 16, 32))
+    anchor = np_ref.enumerate_shifted_anchor(ab, 16, 20, 30)
+    bbox = np.array([[30, 40, 200, 260], [100, 300, 250, 420]], np.float32)
+    loc, label = np_ref.AnchorTargetCreator()(bbox, anchor, (320, 480))
+    assert loc.shape == (len(anchor), 4) and label.shape == (len(anchor),)
+    assert set(np.unique(label)) <= {-1, 0, 1}
+    assert (label == 1).sum() <= 128 and (label >= 0).sum() <= 256
+    assert (label == 1).sum() >= 2   # at least the per-gt argmax anchors
+
+
+def test_resize_bilinear_identity_and_constant():
+    img = np.arange(20, dtype=np.float32).reshape(4, 5)
+    np.testing.assert_allclose(np_ref.resize_bilinear(img, 4, 5), img)
+    const = np.full((9, 7), 3.5, np.float32)
+    np.testing.assert_allclose(np_ref.resize_bilinear(const, 14, 14), 3.5)
+    up = np_ref.resize_bilinear(np.array([[0., 1.]], np.float32), 1, 4)
+    np.testing.assert_allclose(up, [[0., 0.25, 0.75, 1.]])
