@@ -1,0 +1,165 @@
+"""MaskRCNN base model — same interface as the reference's
+/root/reference/chainer_mask_rcnn/models/mask_rcnn.py:110-337 for the hot path
+(``__call__``, ``_to_bboxes`` / ``_suppress`` / ``_to_roi_masks``, ``predict``).
+
+Inference post-processing runs on the device: softmax, per-class decode+clip, a batched
+per-class stable sort and one batched bit-mask NMS launch for all 80 classes (the
+reference loops over classes in Python on CPU copies, :178-202).  ``prepare`` and
+``segm_results`` (cv2 resize / paste of the final image-size masks) are host-side image
+I/O and are out of the hot-path scope ("next" row f-2); ``predict``
+therefore returns the 14x14 per-detection mask probabilities instead of pasted masks.
+"""
+import numpy as np
+import torch
+
+from .. import functions as F
+from .. import _lib
+from ..functions import proposal_ops as P
+
+
+class MaskRCNN(torch.nn.Module):
+
+    def __init__(self, extractor, rpn, head, mean, min_size=600, max_size=1000,
+                 loc_normalize_mean=(0., 0., 0., 0.),
+                 loc_normalize_std=(0.1, 0.1, 0.2, 0.2), detections_per_im=100):
+        super(MaskRCNN, self).__init__()
+        self.extractor = extractor
+        self.rpn = rpn
+        self.head = head
+
+        self.mean = mean
+        self.min_size = min_size
+        self.max_size = max_size
+        self.loc_normalize_mean = loc_normalize_mean
+        self.loc_normalize_std = loc_normalize_std
+
+        self.nms_thresh = 0.5
+        self.score_thresh = 0.05
+
+        self._detections_per_im = detections_per_im
+
+    @property
+    def n_class(self):
+        # Total number of classes including the background.
+        return self.head.n_class
+
+    def forward(self, x, scales):
+        img_size = x.shape[2:]
+        h = self.extractor(x)
+        rpn_locs, rpn_scores, rois, roi_indices, anchor = self.rpn(h, img_size, scales)
+        roi_cls_locs, roi_scores, roi_masks = self.head(h, rois, roi_indices)
+        return roi_cls_locs, roi_scores, rois, roi_indices, roi_masks
+
+    # ------------------------------------------------------------------ inference
+    def _suppress(self, cls_bbox, prob):
+        """Per-class score threshold + NMS (:178-202) for one image, all classes batched.
+
+        cls_bbox (R, n_class, 4), prob (R, n_class) device tensors.  Returns host arrays
+        bbox (D,4) f32, label (D,) i32, score (D,) f32 ordered by class then by score."""
+        R = cls_bbox.shape[0]
+        n_fg = self.n_class - 1
+        dev = cls_bbox.device
+        sorted_boxes = torch.zeros((n_fg, R, 4), dtype=torch.float32, device=dev)
+        sorted_prob = torch.zeros((n_fg, R), dtype=torch.float32, device=dev)
+        counts = torch.zeros((n_fg,), dtype=torch.int32, device=dev)
+        probT = prob.t().contiguous()                       # (n_class, R)
+        boxT = cls_bbox.permute(1, 0, 2).contiguous()       # (n_class, R, 4)
+        for l in range(1, self.n_class):
+            valid = (probT[l] > self.score_thresh).to(torch.uint8)
+            order, n_out = P.topk_desc(probT[l], R, valid)
+            sorted_boxes[l - 1] = P.gather_rows(boxT[l], order, n_out)
+            sorted_prob[l - 1] = P.gather_rows(probT[l][:, None].contiguous(), order, n_out)[:, 0]
+            counts[l - 1:l] = n_out
+        keep, n_keep = P.nms_sorted_batched(sorted_boxes, counts, self.nms_thresh)
+        keep, n_keep = keep.cpu().numpy(), n_keep.cpu().numpy()
+        sorted_boxes, sorted_prob = sorted_boxes.cpu().numpy(), sorted_prob.cpu().numpy()
+        bbox, label, score = [], [], []
+        for l in range(n_fg):
+            k = keep[l, :n_keep[l]]
+            bbox.append(sorted_boxes[l, k])
+            label.append(np.full((len(k),), l, dtype=np.int32))
+            score.append(sorted_prob[l, k])
+        return (np.concatenate(bbox, 0).astype(np.float32),
+                np.concatenate(label, 0).astype(np.int32),
+                np.concatenate(score, 0).astype(np.float32))
+
+    def _to_bboxes(self, roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales):
+        probs = F.softmax(roi_scores.detach())
+        roi_cls_locs = roi_cls_locs.detach()
+        if roi_cls_locs.stride(1) != 1:
+            roi_cls_locs = roi_cls_locs.contiguous()
+        mean = (_lib.c_f32 * 4)(*self.loc_normalize_mean)
+        std = (_lib.c_f32 * 4)(*self.loc_normalize_std)
+        bboxes, labels, scores = [], [], []
+        for index in range(len(sizes)):
+            scale = float(scales[index])
+            size = sizes[index]
+            keep = (roi_indices == index)
+            roi = rois[keep].contiguous()
+            loc = roi_cls_locs[keep]
+            prob = probs[keep].contiguous()
+            R = roi.shape[0]
+            cls_bbox = torch.empty((R, self.n_class, 4), dtype=torch.float32, device=roi.device)
+            if loc.stride(1) != 1 or loc.stride(0) != loc.shape[1]:
+                loc = loc.contiguous()
+            _lib.call('mrcnn_decode_cls_boxes', _lib.ptr(roi), _lib.ptr(loc), loc.stride(0),
+                      _lib.ptr(cls_bbox), R, self.n_class, scale, mean, std,
+                      float(size[0]), float(size[1]), _lib.stream_ptr())
+            bbox, label, score = self._suppress(cls_bbox, prob)
+
+            bbox_int = np.round(bbox).astype(np.int32)
+            bbox_sizes = ((bbox_int[:, 2] - bbox_int[:, 0]) * (bbox_int[:, 3] - bbox_int[:, 1]))
+            ok = bbox_sizes > 0
+            bbox, label, score = bbox[ok], label[ok], score[ok]
+
+            if self._detections_per_im > 0:
+                # literal restatement of models/mask_rcnn.py:255-260 (an argsort
+                # permutation compared with a rank threshold)
+                indices = np.argsort(score, kind='stable')
+                ok = indices >= (len(indices) - self._detections_per_im)
+                bbox, label, score = bbox[ok], label[ok], score[ok]
+
+            bboxes.append(bbox)
+            labels.append(label)
+            scores.append(score)
+        return bboxes, labels, scores
+
+    def _to_roi_masks(self, h, bboxes, roi_indices, scales):
+        batch_size = h.shape[0]
+        bboxes = np.concatenate(bboxes, axis=0)
+        if bboxes.size == 0:
+            n_fg_class = self.n_class - 1
+            mask_size = self.head.mask_size
+            return [np.zeros((0, n_fg_class, mask_size, mask_size), dtype=np.float32)
+                    for _ in range(batch_size)]
+        with torch.no_grad():
+            scales = np.asarray(scales, dtype=np.float32)
+            rois = bboxes * scales[roi_indices][:, None]
+            rois = torch.tensor(rois, dtype=torch.float32, device=h.device)
+            _, _, roi_masks = self.head(
+                h, rois, torch.tensor(roi_indices, device=h.device), pred_bbox=False)
+        roi_masks = roi_masks.cpu().numpy()
+        return [roi_masks[roi_indices == i] for i in range(batch_size)]
+
+    def predict_prepared(self, x, scales, sizes):
+        """The device part of ``predict`` (:311-335) on an already prepared, zero-padded
+        batch x (N,3,H,W) with per-image ``scales`` and original ``sizes`` (H,W).
+
+        Returns (bboxes, roi_mask_logits, labels, scores): per-image lists of host arrays;
+        roi_mask_logits[i] is (D_i, n_fg_class, 14, 14)."""
+        was_training = self.training
+        self.eval()
+        try:
+            with torch.no_grad():
+                h = self.extractor(x)
+                rpn_locs, rpn_scores, rois, roi_indices, anchor = self.rpn(
+                    h, x.shape[2:], scales)
+                roi_cls_locs, roi_scores, _ = self.head(h, rois, roi_indices, pred_mask=False)
+            bboxes, labels, scores = self._to_bboxes(
+                roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales)
+            roi_indices = np.concatenate(
+                [np.full((len(b),), i, dtype=np.int32) for i, b in enumerate(bboxes)], axis=0)
+            roi_masks = self._to_roi_masks(h, bboxes, roi_indices, scales)
+        finally:
+            self.train(was_training)
+        return bboxes, roi_masks, labels, scores

@@ -1,0 +1,103 @@
+"""MaskRCNNTrainChain — same interface and call sequence as the reference's
+/root/reference/chainer_mask_rcnn/models/mask_rcnn_train_chain.py:25-189.
+
+forward(imgs, bboxes, labels, masks, scales) -> scalar loss (sum of the five losses);
+the six reported scalars are kept in ``self.report`` (device tensors, no sync) as the
+reference reports them through chainer.reporter (:182-188).
+"""
+import numpy as np
+import torch
+
+from .. import functions as F
+from .utils import AnchorTargetCreator
+from .utils import ProposalTargetCreator
+
+
+class MaskRCNNTrainChain(torch.nn.Module):
+
+    def __init__(self, mask_rcnn, rpn_sigma=3., roi_sigma=1.,
+                 anchor_target_creator=None, proposal_target_creator=None):
+        super(MaskRCNNTrainChain, self).__init__()
+        self.mask_rcnn = mask_rcnn
+        self.rpn_sigma = rpn_sigma
+        self.roi_sigma = roi_sigma
+        self.anchor_target_creator = anchor_target_creator or AnchorTargetCreator()
+        self.proposal_target_creator = proposal_target_creator or ProposalTargetCreator()
+        self.loc_normalize_mean = mask_rcnn.loc_normalize_mean
+        self.loc_normalize_std = mask_rcnn.loc_normalize_std
+        self.report = {}
+
+    def forward(self, imgs, bboxes, labels, masks, scales):
+        """imgs (N,3,H,W) device tensor; bboxes / labels / masks: per-image sequences of
+        host (or device) arrays (G,4) f32 / (G,) i32 / (G,H,W) i32; scales (N,) floats."""
+        scales = np.asarray([float(s) for s in scales], dtype=np.float32)
+        to_np = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        bboxes = [to_np(b).astype(np.float32) for b in bboxes]
+        labels = [to_np(l).astype(np.int32) for l in labels]
+        dev = imgs.device
+
+        batch_size, _, H, W = imgs.shape
+        img_size = (H, W)
+
+        features = self.mask_rcnn.extractor(imgs)
+        rpn_locs, rpn_scores, rois, roi_indices, anchor = self.mask_rcnn.rpn(
+            features, img_size, scales)
+
+        # proposal targets: host-side sampling, exactly as the reference (:126-146)
+        rois_h = rois.cpu().numpy()
+        roi_indices_h = roi_indices.cpu().numpy()
+        sample_rois, sample_roi_indices = [], []
+        gt_roi_locs, gt_roi_labels, gt_roi_masks = [], [], []
+        for batch_index, (bbox, label, mask) in enumerate(zip(bboxes, labels, masks)):
+            roi = rois_h[roi_indices_h == batch_index]
+            sample_roi, gt_roi_loc, gt_roi_label, gt_roi_mask = \
+                self.proposal_target_creator(roi, bbox, label, to_np(mask))
+            sample_rois.append(sample_roi)
+            sample_roi_indices.append(np.full((len(sample_roi),), batch_index, dtype=np.int32))
+            gt_roi_locs.append(gt_roi_loc)
+            gt_roi_labels.append(gt_roi_label)
+            gt_roi_masks.append(gt_roi_mask)
+        up = lambda parts, dt: torch.tensor(np.concatenate(parts, axis=0), dtype=dt, device=dev)
+        sample_rois = up(sample_rois, torch.float32)
+        sample_roi_indices = up(sample_roi_indices, torch.int32)
+        gt_roi_locs = up(gt_roi_locs, torch.float32)
+        gt_roi_labels = up(gt_roi_labels, torch.int32)
+        gt_roi_masks = up(gt_roi_masks, torch.int32)
+
+        roi_cls_locs, roi_scores, roi_masks = self.mask_rcnn.head(
+            features, sample_rois, sample_roi_indices)
+
+        # RPN targets (host) — after all ProposalTargetCreator calls, as in the reference,
+        # so the global np.random stream is consumed in the same order (:150-158).
+        anchor_h = self.mask_rcnn.rpn.host_anchor(features.shape[2], features.shape[3], dev)
+        gt_rpn_locs, gt_rpn_labels = [], []
+        for bbox in bboxes:
+            gt_rpn_loc, gt_rpn_label = self.anchor_target_creator(bbox, anchor_h, img_size)
+            gt_rpn_locs.append(gt_rpn_loc)
+            gt_rpn_labels.append(gt_rpn_label)
+        gt_rpn_locs = up(gt_rpn_locs, torch.float32)
+        gt_rpn_labels = up(gt_rpn_labels, torch.int32)
+        rpn_locs = rpn_locs.reshape(-1, 4)
+        rpn_scores = rpn_scores.reshape(-1)
+        rpn_loc_loss = F.fast_rcnn_loc_loss(rpn_locs, gt_rpn_locs, gt_rpn_labels, self.rpn_sigma)
+        rpn_cls_loss = F.sigmoid_cross_entropy(rpn_scores, gt_rpn_labels)
+
+        # Losses for outputs of the head: the class-specific 4-vector is selected inside
+        # the kernel (roi_cls_locs[arange(n), gt_roi_labels], :168-170).
+        roi_loc_loss = F.fast_rcnn_loc_loss(
+            roi_cls_locs, gt_roi_locs, gt_roi_labels, self.roi_sigma, cls=gt_roi_labels)
+        roi_cls_loss = F.softmax_cross_entropy(roi_scores, gt_roi_labels)
+
+        # Losses for outputs of mask branch (:176-178)
+        roi_mask_loss = F.mask_sigmoid_cross_entropy(roi_masks, gt_roi_labels, gt_roi_masks)
+
+        loss = rpn_loc_loss + rpn_cls_loss + roi_loc_loss + roi_cls_loss + roi_mask_loss
+        self.report = {'rpn_loc_loss': rpn_loc_loss.detach(),
+                       'rpn_cls_loss': rpn_cls_loss.detach(),
+                       'roi_loc_loss': roi_loc_loss.detach(),
+                       'roi_cls_loss': roi_cls_loss.detach(),
+                       'roi_mask_loss': roi_mask_loss.detach(),
+                       'loss': loss.detach()}
+        self.last_targets = {'sample_rois': sample_rois, 'gt_roi_labels': gt_roi_labels,
+                             'n_rois': int(sample_rois.shape[0])}
+        return loss

@@ -1,0 +1,175 @@
+"""ResNet-50/101 C4 extractor — same structure, parameter names and semantics as the
+reference's /root/reference/chainer_mask_rcnn/models/resnet_extractor.py:47-124 built on
+chainer's ResNet50Layers / BuildingBlock / BottleneckA/B:
+
+  conv1 7x7/2 (+bias) -> bn1 (AffineChannel2D) -> relu -> max-pool 3x3/2 pad 1 (cover_all)
+  -> res2 (3 blocks) [no gradient below: unchain_backward at freeze_at='res2']
+  -> res3 (4 blocks, stride 2 in the first 1x1) -> res4 (6 | 23 blocks) = target layer.
+
+Every BatchNormalization is an AffineChannel2D (:32-44) and is fused into the epilogue of
+the convolution it follows, together with the residual add and ReLU, so one bottleneck is
+three (or four) launches of the implicit-GEMM kernel and nothing else.
+"""
+import collections
+import math
+
+import torch
+
+from .. import functions as F
+from ..links import AffineChannel2D
+
+
+def _he_normal_(w, fan_in):
+    with torch.no_grad():
+        w.normal_(0., math.sqrt(2. / fan_in))
+
+
+class Convolution2D(torch.nn.Module):
+    """Parameter holder mirroring ``L.Convolution2D`` (W (out,in,kh,kw), optional b),
+    stored channels-last = KRSC."""
+
+    def __init__(self, in_ch, out_ch, ksize, stride=1, pad=0, nobias=False, std=None):
+        super(Convolution2D, self).__init__()
+        w = torch.empty((out_ch, ksize, ksize, in_ch), dtype=torch.float32).permute(0, 3, 1, 2)
+        self.W = torch.nn.Parameter(w)
+        if std is None:
+            _he_normal_(self.W, in_ch * ksize * ksize)
+        else:
+            with torch.no_grad():
+                self.W.normal_(0., std)
+        self.b = None if nobias else torch.nn.Parameter(torch.zeros(out_ch))
+        self.stride, self.pad = stride, pad
+
+    def forward(self, x, affine=None, residual=None, relu=False):
+        scale = shift = None
+        if affine is not None:
+            scale, shift = affine.W, affine.b
+        return F.conv2d(x, self.W, self.b, self.stride, self.pad, scale=scale, shift=shift,
+                        residual=residual, relu=relu)
+
+
+class Bottleneck(torch.nn.Module):
+    """chainer BottleneckA (with projection shortcut conv4/bn4) or BottleneckB."""
+
+    def __init__(self, in_ch, mid_ch, out_ch, stride=1, projection=False):
+        super(Bottleneck, self).__init__()
+        self.conv1 = Convolution2D(in_ch, mid_ch, 1, stride, 0, nobias=True)
+        self.bn1 = AffineChannel2D(mid_ch)
+        self.conv2 = Convolution2D(mid_ch, mid_ch, 3, 1, 1, nobias=True)
+        self.bn2 = AffineChannel2D(mid_ch)
+        self.conv3 = Convolution2D(mid_ch, out_ch, 1, 1, 0, nobias=True)
+        self.bn3 = AffineChannel2D(out_ch)
+        self.projection = projection
+        if projection:
+            self.conv4 = Convolution2D(in_ch, out_ch, 1, stride, 0, nobias=True)
+            self.bn4 = AffineChannel2D(out_ch)
+
+    def forward(self, x):
+        h = self.conv1(x, self.bn1, relu=True)
+        h = self.conv2(h, self.bn2, relu=True)
+        shortcut = self.conv4(x, self.bn4) if self.projection else x
+        return self.conv3(h, self.bn3, residual=shortcut, relu=True)
+
+
+class BuildingBlock(torch.nn.Module):
+    """chainer BuildingBlock(n_layer, in, mid, out, stride): children a, b1 .. b{n-1}."""
+
+    def __init__(self, n_layer, in_ch, mid_ch, out_ch, stride):
+        super(BuildingBlock, self).__init__()
+        self.a = Bottleneck(in_ch, mid_ch, out_ch, stride, projection=True)
+        self._names = ['a']
+        for i in range(n_layer - 1):
+            name = 'b{}'.format(i + 1)
+            setattr(self, name, Bottleneck(out_ch, mid_ch, out_ch))
+            self._names.append(name)
+
+    def forward(self, x):
+        for name in self._names:
+            x = getattr(self, name)(x)
+        return x
+
+
+def pad_image_nhwc4(x):
+    """(N,3,H,W) logical NCHW image -> dense (N,H,W,4) with a zero 4th channel."""
+    n, c, h, w = x.shape
+    assert c == 3
+    out = torch.zeros((n, h, w, 4), dtype=torch.float32, device=x.device)
+    out[..., :3] = x.permute(0, 2, 3, 1)
+    return out
+
+
+def pack_stem_filter(W):
+    """conv1 filter (K,3,7,7) -> (K,7,8,4) with zeros at s=7 and c=3 (stem kernel layout)."""
+    k = W.shape[0]
+    out = torch.zeros((k, 7, 8, 4), dtype=torch.float32, device=W.device)
+    out[:, :, :7, :3] = W.detach().permute(0, 2, 3, 1)
+    return out
+
+
+class ResNetExtractorBase(torch.nn.Module):
+
+    target_layer = 'res4'
+    freeze_at = 'res2'
+    _blocks = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3]}
+
+    def __init__(self, n_layers, remove_layers=None):
+        super(ResNetExtractorBase, self).__init__()
+        n = self._blocks[n_layers]
+        self.conv1 = Convolution2D(3, 64, 7, 2, 3)
+        self.bn1 = AffineChannel2D(64)
+        self.res2 = BuildingBlock(n[0], 64, 64, 256, 1)
+        self.res3 = BuildingBlock(n[1], 256, 128, 512, 2)
+        self.res4 = BuildingBlock(n[2], 512, 256, 1024, 2)
+        self.res5 = None
+        if not remove_layers or 'res5' not in remove_layers:
+            self.res5 = BuildingBlock(n[3], 1024, 512, 2048, 2)
+        self._stem_cache = None
+
+    def _stem(self, x):
+        # conv1 and bn1 are frozen (examples/train_common.py:185-187): pack once per weight version
+        W = self.conv1.W
+        key = (W._version, W.data_ptr(), str(W.device))
+        if self._stem_cache is None or self._stem_cache[0] != key:
+            self._stem_cache = (key, pack_stem_filter(W))
+        x4 = pad_image_nhwc4(x)
+        return F.stem_conv(x4, self._stem_cache[1], self.conv1.b.detach(),
+                           self.bn1.W.detach(), self.bn1.b.detach())
+
+    @property
+    def functions(self):
+        return collections.OrderedDict([
+            ('conv1', [self._stem]),
+            ('pool1', [lambda x: F.max_pooling_2d(x, 3, stride=2, pad=1)]),
+            ('res2', [self.res2]),
+            ('res3', [self.res3]),
+            ('res4', [self.res4]),
+            ('res5', [self.res5]),
+        ])
+
+    def forward(self, x):
+        assert self.freeze_at is None or self.freeze_at in self.functions
+        h = x
+        frozen = self.freeze_at is not None
+        for key, funcs in self.functions.items():
+            for func in funcs:
+                if frozen:
+                    with torch.no_grad():
+                        h = func(h)
+                else:
+                    h = func(h)
+            if key == self.freeze_at:
+                h = h.detach()          # Variable.unchain_backward()
+                frozen = False
+            if key == self.target_layer:
+                break
+        return h
+
+
+class ResNet50Extractor(ResNetExtractorBase):
+    def __init__(self, pretrained_model=None, remove_layers=None):
+        super(ResNet50Extractor, self).__init__(50, remove_layers)
+
+
+class ResNet101Extractor(ResNetExtractorBase):
+    def __init__(self, pretrained_model=None, remove_layers=None):
+        super(ResNet101Extractor, self).__init__(101, remove_layers)

@@ -1,0 +1,43 @@
+"""ProposalCreator on the device — chainercv's proposal layer (un-vendored dependency;
+ctor /root/reference/chainer_mask_rcnn/models/region_proposal_network.py:70 with the
+parameters of models/mask_rcnn_resnet.py:48-52, per-image call :135-138; algorithm
+SURVEY.md Appendix A.4).  Upstream copies loc/score/anchor to the host, sorts with
+NumPy and scans the NMS bit-mask in Python; here every step is a HIP kernel and the
+only host round trip is the final kept-count."""
+import torch
+
+from ...functions import proposal_ops as P
+
+
+class ProposalCreator(object):
+
+    def __init__(self, nms_thresh=0.7, n_train_pre_nms=12000, n_train_post_nms=2000,
+                 n_test_pre_nms=6000, n_test_post_nms=300, force_cpu_nms=False, min_size=16):
+        self.nms_thresh = nms_thresh
+        self.n_train_pre_nms = n_train_pre_nms
+        self.n_train_post_nms = n_train_post_nms
+        self.n_test_pre_nms = n_test_pre_nms
+        self.n_test_post_nms = n_test_post_nms
+        self.force_cpu_nms = force_cpu_nms   # accepted for interface parity; no CPU path exists
+        self.min_size = min_size
+        self.train = True                    # chainer.config.train
+
+    def __call__(self, loc, score, anchor, img_size, scale=1., return_indices=False):
+        """loc (S,4), score (S,), anchor (S,4) device tensors -> roi (R,4) device tensor."""
+        if self.train:
+            n_pre, n_post = self.n_train_pre_nms, self.n_train_post_nms
+        else:
+            n_pre, n_post = self.n_test_pre_nms, self.n_test_post_nms
+        loc = loc.detach()
+        score = score.detach().reshape(-1)
+        roi, valid = P.decode_clip(anchor, loc, img_size, float(self.min_size) * float(scale))
+        order, n_sorted = P.topk_desc(score, n_pre if n_pre > 0 else score.numel(), valid)
+        sorted_roi = P.gather_rows(roi, order, n_sorted)
+        keep, n_keep = P.nms_sorted(sorted_roi, self.nms_thresh, n_sorted,
+                                    limit=n_post if n_post > 0 else 0)
+        nk = int(n_keep.item())              # the one host synchronisation
+        keep = keep[:nk].contiguous()
+        out = P.gather_rows(sorted_roi, keep)
+        if return_indices:
+            return out, order[keep.long()]
+        return out

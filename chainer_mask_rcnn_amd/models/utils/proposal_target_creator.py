@@ -1,0 +1,80 @@
+"""ProposalTargetCreator — same interface and sampling semantics as the reference's
+/root/reference/chainer_mask_rcnn/models/utils/proposal_target_creator.py:23-184.
+
+Host-side NumPy, exactly like the reference (which always moves its inputs to the
+CPU, :112-115): integer/sampling work whose results depend on the *global*
+``np.random`` stream (seeded at examples/train_common.py:135-136), so the order of
+``np.random.choice`` calls is kept: foreground first, then background.
+"""
+import numpy as np
+
+from ...utils.bbox import bbox_iou, bbox2loc, resize_bilinear
+
+
+class ProposalTargetCreator(object):
+    """Assign ground truth boxes, labels and 14x14 masks to sampled RoIs."""
+
+    def __init__(self, n_sample=512, pos_ratio=0.25, pos_iou_thresh=0.5,
+                 neg_iou_thresh_hi=0.5, neg_iou_thresh_lo=0.0,
+                 mask_size=14, binary_thresh=0.4):
+        self.n_sample = n_sample
+        self.pos_ratio = pos_ratio
+        self.pos_iou_thresh = pos_iou_thresh
+        self.neg_iou_thresh_hi = neg_iou_thresh_hi
+        self.neg_iou_thresh_lo = neg_iou_thresh_lo
+        self.mask_size = mask_size
+        self.binary_thresh = binary_thresh
+
+    def __call__(self, roi, bbox, label, mask,
+                 loc_normalize_mean=(0., 0., 0., 0.),
+                 loc_normalize_std=(0.1, 0.1, 0.2, 0.2)):
+        """roi (R,4), bbox (G,4), label (G,), mask (G,H,W) host arrays ->
+        sample_roi (S,4) f32, gt_roi_loc (S,4) f32, gt_roi_label (S,) i32 (0 = bg),
+        gt_roi_mask (S,14,14) i32 in {-1,0,1}."""
+        roi = np.asarray(roi, np.float32)
+        bbox = np.asarray(bbox, np.float32)
+        label = np.asarray(label)
+        if bbox.shape[0] == 0:
+            raise ValueError('Empty bbox is not supported.')
+
+        # ground-truth boxes are candidates too (:121)
+        cand = np.concatenate((roi, bbox), axis=0)
+        n_pos_max = np.round(self.n_sample * self.pos_ratio)
+        iou = bbox_iou(cand, bbox)
+        assigned = iou.argmax(axis=1)
+        best = iou.max(axis=1)
+        cand_label = label[assigned] + 1          # 0 is background (:129)
+
+        fg = np.where(best >= self.pos_iou_thresh)[0]
+        n_fg = int(min(n_pos_max, fg.size))
+        if fg.size > 0:
+            fg = np.random.choice(fg, size=n_fg, replace=False)
+
+        bg = np.where((best < self.neg_iou_thresh_hi) & (best >= self.neg_iou_thresh_lo))[0]
+        n_bg = int(min(self.n_sample - n_fg, bg.size))
+        if bg.size > 0:
+            bg = np.random.choice(bg, size=n_bg, replace=False)
+
+        chosen = np.append(fg, bg)
+        gt_roi_label = cand_label[chosen].astype(np.int32)
+        gt_roi_label[n_fg:] = 0
+        sample_roi = cand[chosen]
+
+        gt_roi_loc = bbox2loc(sample_roi, bbox[assigned[chosen]])
+        gt_roi_loc = ((gt_roi_loc - np.array(loc_normalize_mean, np.float32)) /
+                      np.array(loc_normalize_std, np.float32)).astype(np.float32)
+
+        # 14x14 mask targets for the foreground RoIs; background rows stay -1 (:160-177).
+        # The reference one-hot encodes the {0,1} crop, resizes both channels with
+        # bilinear weights (which sum to 1) and takes the argmax, i.e. fg prob > 0.5.
+        M = self.mask_size
+        gt_roi_mask = -np.ones((len(sample_roi), M, M), dtype=np.int32)
+        for i, idx in enumerate(fg):
+            y0, x0, y1, x1 = np.round(sample_roi[i]).astype(np.int32)
+            crop = mask[assigned[idx]][y0:y1, x0:x1]
+            if crop.size == 0 or crop.max() <= 0:
+                gt_roi_mask[i] = 0
+                continue
+            prob = resize_bilinear((crop > 0).astype(np.float32), M, M)
+            gt_roi_mask[i] = (prob > 0.5).astype(np.int32)
+        return sample_roi, gt_roi_loc, gt_roi_label, gt_roi_mask

@@ -1,0 +1,88 @@
+"""Host-side (NumPy) box utilities used by the target creators.
+
+The reference takes these from chainercv (``generate_anchor_base``, ``bbox_iou``,
+``bbox2loc``; imports at /root/reference/chainer_mask_rcnn/models/region_proposal_network.py:20-23
+and models/utils/proposal_target_creator.py:19-20) and runs them on the CPU with
+NumPy as well (proposal_target_creator.py:112-115), so they stay host code here.
+Boxes are (y_min, x_min, y_max, x_max) float32.
+"""
+import numpy as np
+
+
+def generate_anchor_base(base_size=16, ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32)):
+    """(len(ratios)*len(scales), 4) anchors centred on (base/2, base/2), ratio-major."""
+    r = np.asarray(ratios, dtype=np.float64)[:, None]
+    s = np.asarray(anchor_scales, dtype=np.float64)[None, :]
+    h = (base_size * s * np.sqrt(r)).ravel()
+    w = (base_size * s * np.sqrt(1. / r)).ravel()
+    c = base_size / 2.
+    return np.stack([c - h / 2., c - w / 2., c + h / 2., c + w / 2.], axis=1).astype(np.float32)
+
+
+def enumerate_shifted_anchor(anchor_base, feat_stride, height, width):
+    """All anchors of an (height, width) feature map, cell-major then anchor
+    (models/region_proposal_network.py:148-167)."""
+    ys = np.arange(0, height * feat_stride, feat_stride)
+    xs = np.arange(0, width * feat_stride, feat_stride)
+    gy, gx = np.meshgrid(ys, xs, indexing='ij')
+    shift = np.stack([gy.ravel(), gx.ravel(), gy.ravel(), gx.ravel()], axis=1)
+    anchor = shift[:, None, :] + anchor_base[None, :, :]
+    return anchor.reshape(-1, 4).astype(np.float32)
+
+
+def bbox_iou(bbox_a, bbox_b):
+    """(len(a), len(b)) IoU matrix, no +1 terms."""
+    if bbox_a.shape[1] != 4 or bbox_b.shape[1] != 4:
+        raise IndexError
+    tl = np.maximum(bbox_a[:, None, :2], bbox_b[None, :, :2])
+    br = np.minimum(bbox_a[:, None, 2:], bbox_b[None, :, 2:])
+    inter = np.prod(br - tl, axis=2) * (tl < br).all(axis=2)
+    area_a = np.prod(bbox_a[:, 2:] - bbox_a[:, :2], axis=1)
+    area_b = np.prod(bbox_b[:, 2:] - bbox_b[:, :2], axis=1)
+    return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+
+def bbox2loc(src_bbox, dst_bbox):
+    """Offsets/scales (dy, dx, dh, dw) that map src boxes onto dst boxes."""
+    src = np.asarray(src_bbox, np.float32)
+    dst = np.asarray(dst_bbox, np.float32)
+    half = np.float32(0.5)
+    sh, sw = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    scy, scx = src[:, 0] + half * sh, src[:, 1] + half * sw
+    dh_, dw_ = dst[:, 2] - dst[:, 0], dst[:, 3] - dst[:, 1]
+    dcy, dcx = dst[:, 0] + half * dh_, dst[:, 1] + half * dw_
+    eps = np.finfo(np.float32).eps
+    sh, sw = np.maximum(sh, eps), np.maximum(sw, eps)
+    out = np.empty((len(src), 4), np.float32)
+    out[:, 0] = (dcy - scy) / sh
+    out[:, 1] = (dcx - scx) / sw
+    out[:, 2] = np.log(dh_ / sh)
+    out[:, 3] = np.log(dw_ / sw)
+    return out
+
+
+def resize_bilinear(img, out_h, out_w):
+    """OpenCV ``cv2.resize(img, (out_w, out_h))`` INTER_LINEAR rule for a float32
+    2-D image: src = (dst + 0.5) * scale - 0.5, clamped to the border (cv2 is what
+    the reference uses at models/utils/proposal_target_creator.py:171-172; it is
+    not installable here)."""
+    img = np.asarray(img, np.float32)
+    h, w = img.shape[:2]
+
+    def axis(n_out, n_in):
+        pos = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / float(n_out)) - 0.5
+        i0 = np.floor(pos).astype(np.int64)
+        t = (pos - i0).astype(np.float32)
+        below, above = i0 < 0, i0 >= n_in - 1
+        i0 = np.clip(i0, 0, n_in - 1)
+        t[below | above] = 0.
+        return i0, np.minimum(i0 + 1, n_in - 1), t
+
+    y0, y1, ty = axis(out_h, h)
+    x0, x1, tx = axis(out_w, w)
+    ty = ty[:, None]
+    tx = tx[None, :]
+    r0, r1 = img[y0], img[y1]
+    top = r0[:, x0] * (1 - tx) + r0[:, x1] * tx
+    bot = r1[:, x0] * (1 - tx) + r1[:, x1] * tx
+    return (top * (1 - ty) + bot * ty).astype(np.float32)

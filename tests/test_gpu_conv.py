@@ -1,0 +1,180 @@
+"""fp32-MFMA implicit-GEMM convolution family vs the NumPy oracle (np_ref) on the
+same seeded inputs.  Tolerance: north_star's 1e-4 relative for fp32 conv (applied
+against the tensor's scale: GEMM summation order differs from BLAS')."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ref
+from chainer_mask_rcnn_amd import functions as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, rel=1e-4):
+    scale = max(np.abs(ref).max(), 1e-6)
+    err = np.abs(got - ref).max()
+    assert err <= rel * scale, 'max err %.3e vs scale %.3e' % (err, scale)
+
+
+def _t(a, dev, grad=False):
+    t = torch.tensor(a, device=dev)
+    if grad:
+        t.requires_grad_(True)
+    return t
+
+
+CASES = [
+    # N, C, H, W, K, k, stride, pad
+    (2, 64, 13, 17, 96, 1, 1, 0),
+    (2, 64, 13, 17, 64, 3, 1, 1),
+    (1, 256, 21, 34, 128, 1, 2, 0),      # strided 1x1 (res3.a.conv1 style)
+    (3, 128, 14, 14, 132, 3, 1, 1),      # K not multiple of 32/64
+    (2, 36, 9, 11, 40, 3, 1, 1),         # C not multiple of 32 (K-slice tail)
+    (1, 1024, 26, 42, 256, 1, 1, 0),     # deep K, 128x128 tiles
+    (4, 512, 14, 14, 512, 3, 1, 1),
+    (300, 128, 7, 7, 256, 1, 1, 0),      # many small images (RoI-batch shape)
+    (2, 256, 14, 14, 80, 1, 1, 0),       # mask-head 1x1, 80 classes
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    N, C, H, W, K, k, s, p = case
+    rng = np.random.RandomState(sum(case))
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((K, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    xt, wt, bt = _t(x, dev, True), _t(Wt, dev, True), _t(b, dev, True)
+    y = F.conv2d(xt, wt, bt, stride=s, pad=p)
+    y_ref = np_ref.conv2d_fwd(x, Wt, b, s, p)
+    _close(y.detach().cpu().numpy(), y_ref)
+    gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    y.backward(_t(gy, dev))
+    gx, gW, gb = np_ref.conv2d_bwd(x, Wt, gy, s, p)
+    _close(xt.grad.cpu().numpy(), gx)
+    _close(wt.grad.cpu().numpy(), gW)
+    _close(bt.grad.cpu().numpy(), gb)
+
+
+def test_conv_fused_epilogue_and_backward(dev):
+    """relu(affine(conv(x)) + residual): forward and all input gradients."""
+    rng = np.random.RandomState(3)
+    N, C, H, W, K = 2, 64, 12, 15, 128
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((K, C, 3, 3)) / 24.).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = rng.standard_normal(K).astype(np.float32)
+    res = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    xt, wt, rt = _t(x, dev, True), _t(Wt, dev, True), _t(res, dev, True)
+    y = F.conv2d(xt, wt, None, 1, 1, scale=_t(sc, dev), shift=_t(sh, dev), residual=rt, relu=True)
+    pre = np_ref.affine_channel_2d_fwd(np_ref.conv2d_fwd(x, Wt, None, 1, 1), sc, sh) + res
+    y_ref = np.maximum(pre, 0)
+    _close(y.detach().cpu().numpy(), y_ref)
+    gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    y.backward(_t(gy, dev))
+    gr = gy * (pre > 0)
+    g = gr * sc[None, :, None, None]
+    gx, gW, _ = np_ref.conv2d_bwd(x, Wt, g, 1, 1)
+    _close(rt.grad.cpu().numpy(), gr)
+    _close(xt.grad.cpu().numpy(), gx)
+    _close(wt.grad.cpu().numpy(), gW)
+
+
+def test_deconv2x2s2(dev):
+    rng = np.random.RandomState(4)
+    N, C, H, W, K = 5, 256, 7, 7, 64
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((C, K, 2, 2)) / 16.).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    xt, wt, bt = _t(x, dev, True), _t(Wt, dev, True), _t(b, dev, True)
+    y = F.deconv2x2s2(xt, wt, bt, relu=True)
+    pre = np_ref.deconv2x2s2_fwd(x, Wt, b)
+    _close(y.detach().cpu().numpy(), np.maximum(pre, 0))
+    gy = rng.standard_normal(pre.shape).astype(np.float32)
+    y.backward(_t(gy, dev))
+    g = gy * (pre > 0)
+    gx, gW, gb = np_ref.deconv2x2s2_bwd(x, Wt, g)
+    _close(xt.grad.cpu().numpy(), gx)
+    _close(wt.grad.cpu().numpy(), gW)
+    _close(bt.grad.cpu().numpy(), gb)
+
+
+def test_linear(dev):
+    rng = np.random.RandomState(5)
+    R, Cin, Cout = 300, 2048, 408
+    x = rng.standard_normal((R, Cin)).astype(np.float32)
+    Wt = (rng.standard_normal((Cout, Cin)) / 45.).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    xt, wt, bt = _t(x, dev, True), _t(Wt, dev, True), _t(b, dev, True)
+    y = F.linear(xt, wt, bt)
+    _close(y.detach().cpu().numpy(), np_ref.linear_fwd(x, Wt, b))
+    gy = rng.standard_normal((R, Cout)).astype(np.float32)
+    y.backward(_t(gy, dev))
+    _close(xt.grad.cpu().numpy(), gy @ Wt)
+    _close(wt.grad.cpu().numpy(), gy.T @ x)
+    _close(bt.grad.cpu().numpy(), gy.sum(0))
+
+
+def test_stem_conv(dev):
+    """conv1 7x7/2 pad 3 + bias + affine + relu on a 3-channel image."""
+    from chainer_mask_rcnn_amd.models.resnet_extractor import pack_stem_filter, pad_image_nhwc4
+    rng = np.random.RandomState(6)
+    N, H, W, K = 2, 61, 83, 64
+    x = rng.uniform(-120, 130, (N, 3, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((K, 3, 7, 7)) / 12.).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = rng.standard_normal(K).astype(np.float32)
+    x4 = pad_image_nhwc4(_t(x, dev))
+    w784 = pack_stem_filter(_t(Wt, dev))
+    y = F.stem_conv(x4, w784, _t(b, dev), _t(sc, dev), _t(sh, dev))
+    ref = np.maximum(np_ref.affine_channel_2d_fwd(np_ref.conv2d_fwd(x, Wt, b, 2, 3), sc, sh), 0)
+    _close(y.cpu().numpy(), ref)
+
+
+def test_pools(dev):
+    rng = np.random.RandomState(7)
+    x = rng.standard_normal((2, 64, 40, 67)).astype(np.float32)
+    y = F.max_pooling_2d(_t(x, dev), 3, stride=2, pad=1)
+    ref = np_ref.max_pooling_2d(x)
+    assert tuple(y.shape) == ref.shape == (2, 64, 21, 34)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    x = rng.standard_normal((50, 2048, 7, 7)).astype(np.float32)
+    xt = _t(x, dev, True)
+    y = F.average_pooling_2d(xt, 7, stride=7)
+    _close(y.detach().cpu().numpy(), np_ref.average_pooling_2d(x, 7, 7))
+    gy = rng.standard_normal((50, 2048, 1, 1)).astype(np.float32)
+    y.backward(_t(gy, dev))
+    _close(xt.grad.cpu().numpy(), np.broadcast_to(gy / 49., x.shape))
+
+
+def test_affine_channel_2d_golden(dev, golden_dir):
+    import os
+    d = np.load(os.path.join(golden_dir, 'affine_channel_2d.npz'))
+    xt, wt, bt = _t(d['x'], dev, True), _t(d['W'], dev, True), _t(d['b'], dev, True)
+    y = F.affine_channel_2d(xt, wt, bt)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), d['y'], rtol=1e-6, atol=1e-6)
+    y.backward(_t(d['gy'], dev))
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), d['gx'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(wt.grad.cpu().numpy(), d['gW'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bt.grad.cpu().numpy(), d['gb'], rtol=1e-4, atol=1e-5)
+
+
+def test_conv_linearity_at_full_size(dev):
+    """Size-independent property at the BASELINE C2 res5 shape (1024 RoIs):
+    conv(a*x1 + x2) == a*conv(x1) + conv(x2) to fp32 round-off, plus a spot check
+    of 64 output pixels against an fp64 dot product."""
+    torch.manual_seed(0)
+    R, C, K = 1024, 512, 512
+    x1 = torch.randn((R, 7, 7, C), device=dev).permute(0, 3, 1, 2)
+    x2 = torch.randn((R, 7, 7, C), device=dev).permute(0, 3, 1, 2)
+    Wt = (torch.randn((K, 3, 3, C), device=dev) / 68.).permute(0, 3, 1, 2)
+    y1, y2 = F.conv2d(x1, Wt, None, 1, 1), F.conv2d(x2, Wt, None, 1, 1)
+    y3 = F.conv2d(1.5 * x1 + x2, Wt, None, 1, 1)
+    err = (y3 - (1.5 * y1 + y2)).abs().max().item()
+    assert err <= 1e-4 * y3.abs().max().item()
+    xs = x1[1000:1001].double().cpu()
+    ws = Wt.double().cpu()
+    ref = torch.nn.functional.conv2d(xs, ws, padding=1)
+    assert (y1[1000:1001].double().cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()

@@ -1,0 +1,94 @@
+"""HIP ROIAlign (through the C ABI) vs the reference's golden vectors and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from chainer_mask_rcnn_amd import functions as F
+
+pytestmark = pytest.mark.gpu
+
+# north_star: within 1e-4 relative for fp32 ROIAlign
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _run(dev, x, rois, outh, outw, scale, sr, gy, axes='xy'):
+    xt = torch.tensor(x, device=dev, requires_grad=True)
+    y = F.roi_align_2d(xt, torch.tensor(rois, device=dev), outh, outw, scale, sr, axes=axes)
+    y.backward(torch.tensor(gy, device=dev))
+    return y.detach().cpu().numpy(), xt.grad.cpu().numpy()
+
+
+@pytest.mark.parametrize('name', ['roi_align_testgeom_sr0', 'roi_align_testgeom_sr1',
+                                  'roi_align_testgeom_sr2', 'roi_align_toy0',
+                                  'roi_align_toy1', 'roi_align_toy2'])
+def test_reference_golden(dev, golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name + '.npz'))
+    y, gx = _run(dev, d['x'], d['rois'], int(d['outh']), int(d['outw']),
+                 float(d['spatial_scale']), int(d['sampling_ratio']), d['gy'])
+    np.testing.assert_allclose(y, d['y'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(gx, d['gx'], rtol=RTOL, atol=ATOL * 10)
+
+
+def test_reference_golden_c4like_yx(dev, golden_dir):
+    d = np.load(os.path.join(golden_dir, 'roi_align_c4like.npz'))
+    y, gx = _run(dev, d['x'], d['rois_yx'], 14, 14, 1. / 16, 0, d['gy'], axes='yx')
+    np.testing.assert_allclose(y, d['y'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(gx, d['gx'], rtol=RTOL, atol=1e-4)
+
+
+@pytest.mark.parametrize('C', [3, 8, 64, 260])
+@pytest.mark.parametrize('sr', [0, 2])
+def test_forward_bit_exact_vs_oracle(dev, C, sr):
+    rng = np.random.RandomState(C + sr)
+    N, H, W = 2, 25, 38
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    R = 40
+    y1 = rng.uniform(0, H * 16, R); x1 = rng.uniform(0, W * 16, R)
+    y2 = np.minimum(y1 + rng.uniform(0, 300, R), H * 16); x2 = np.minimum(x1 + rng.uniform(0, 400, R), W * 16)
+    rois = np.stack([rng.randint(0, N, R), x1, y1, x2, y2], 1).astype(np.float32)
+    gy = rng.standard_normal((R, C, 7, 7)).astype(np.float32)
+    y, gx = _run(dev, x, rois, 7, 7, 1 / 16., sr, gy)
+    y_ref = oracle.roi_align_fwd(x, rois, 7, 7, 1 / 16., sr)
+    assert np.array_equal(y, y_ref)          # same fp32 op order, no FMA: bit-exact
+    gx_ref = oracle.roi_align_bwd(gy, rois, x.shape, 1 / 16., sr)
+    np.testing.assert_allclose(gx, gx_ref, rtol=RTOL, atol=1e-4)
+
+
+def test_out_of_range_samples_skipped(dev):
+    x = np.ones((1, 4, 4, 4), np.float32)
+    rois = np.array([[0, 0, 0, 200, 200], [0, -50, -50, 2, 2]], np.float32)
+    gy = np.ones((2, 4, 2, 2), np.float32)
+    y, gx = _run(dev, x, rois, 2, 2, 1.0, 2, gy)
+    assert np.array_equal(y, oracle.roi_align_fwd(x, rois, 2, 2, 1.0, 2))
+    np.testing.assert_allclose(gx, oracle.roi_align_bwd(gy, rois, x.shape, 1.0, 2), rtol=1e-5, atol=1e-6)
+
+
+def test_empty_rois(dev):
+    x = torch.zeros((1, 8, 5, 5), device=dev, requires_grad=True)
+    y = F.roi_align_2d(x, torch.zeros((0, 5), device=dev), 7, 7, 1.0)
+    assert tuple(y.shape) == (0, 8, 7, 7)
+
+
+def test_gradient_mass_full_size_property(dev):
+    # size-independent property at the BASELINE C2 shape: sum(gx) == sum(gy)
+    # (every sample inside the map) and idempotence of a constant map.
+    torch.manual_seed(0)
+    N, C, H, W, R = 2, 1024, 51, 84, 1024
+    g = torch.Generator(device='cpu').manual_seed(1)
+    yx = torch.rand((R, 2), generator=g) * torch.tensor([700., 1200.])
+    hw = torch.rand((R, 2), generator=g) * torch.tensor([600., 900.]) + 8
+    br = torch.minimum(yx + hw, torch.tensor([800., 1333.]))
+    rois = torch.cat([torch.randint(0, N, (R, 1), generator=g).float(), yx, br], 1).to(dev)
+    x = torch.full((N, C, H, W), 2.5, device=dev).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    y = F.roi_align_2d(x, rois, 14, 14, 1 / 16., axes='yx')
+    assert tuple(y.shape) == (R, C, 14, 14)
+    assert torch.allclose(y, torch.full_like(y, 2.5), rtol=1e-5)
+    gy = torch.randn((R, 14, 14, C), device=dev).permute(0, 3, 1, 2)
+    y.backward(gy)
+    s_gx = x.grad.double().sum().item()
+    s_gy = gy.double().sum().item()
+    assert abs(s_gx - s_gy) <= 1e-4 * gy.double().abs().sum().item()
