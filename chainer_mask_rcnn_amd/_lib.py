@@ -29,6 +29,13 @@ SIGNATURES = {
     'mrcnn_last_error': (ctypes.c_char_p, []),
     'mrcnn_abi_version': (c_int, []),
     'mrcnn_device_info': (c_int, [ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
+    'mrcnn_profile_enable': (c_int, [c_int]),
+    'mrcnn_profile_num_kinds': (c_int, []),
+    'mrcnn_profile_kind_name': (ctypes.c_char_p, [c_int]),
+    'mrcnn_profile_summary': (c_int, [c_int, ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(c_i64)]),
     'mrcnn_roi_align_fwd': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_f32, c_int, c_vp]),
     'mrcnn_roi_align_bwd': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_f32, c_int, c_vp]),
     'mrcnn_affine_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),

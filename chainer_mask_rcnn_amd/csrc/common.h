@@ -39,6 +39,30 @@ inline int check_launch(const char *what)
 
 static inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 
+// ---- in-library kernel timer (HIP events on the launch stream) -----------------
+// bench.py enables it around the timed region to obtain, per kernel kind, the
+// average launch duration and the algorithmic flops / bytes (roofline numbers).
+enum ProfKind {
+    PROF_CONV_FWD_128 = 0, PROF_CONV_FWD_64, PROF_CONV_DGRAD_128, PROF_CONV_DGRAD_64,
+    PROF_CONV_WGRAD_128, PROF_CONV_WGRAD_64, PROF_ROI_ALIGN_FWD, PROF_ROI_ALIGN_BWD,
+    PROF_NMS_MASK, PROF_NMS_SCAN, PROF_TOPK, PROF_SGD, PROF_ELEMENTWISE, PROF_NUM_KINDS
+};
+bool prof_enabled();
+void prof_begin(int kind, double flops, double bytes, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s_;
+    bool on_;
+    ProfScope(int kind, double flops, double bytes, hipStream_t s) : s_(s), on_(prof_enabled())
+    {
+        if (on_) prof_begin(kind, flops, bytes, s);
+    }
+    ~ProfScope()
+    {
+        if (on_) prof_end(s_);
+    }
+};
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace mrcnn

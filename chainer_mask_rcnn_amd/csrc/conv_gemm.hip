@@ -374,7 +374,13 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
 {
     // 128x128 tiles when they fill the chip at least ~1.5x, else 64x64.
     const int64_t big = mrcnn::ceil_div(p.M, 128) * mrcnn::ceil_div(p.N, 128) * splits;
-    if (big >= 384 && p.N > 64 && p.M > 64) {
+    const bool use_big = big >= 384 && p.N > 64 && p.M > 64;
+    const double flops = 2.0 * p.M * p.N * (double)p.R * p.S * (p.stem ? 21.0 : (double)p.Kc);
+    const double bytes = 4.0 * ((double)p.M * p.N + (double)p.M * p.Kc + (double)p.N * p.R * p.S * p.Kc);
+    mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
+                              (use_big ? 0 : 1),
+                          flops, bytes, s);
+    if (use_big) {
         const int64_t blocks = mrcnn::ceil_div(p.M, 128) * mrcnn::ceil_div(p.N, 128);
         hipLaunchKernelGGL((conv_gemm_kernel<2, 2, MODE>), dim3((unsigned)blocks, splits), dim3(256),
                            0, s, p);
@@ -518,7 +524,11 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     p.split_stride = gwsz;
     p.C = splits > 1 ? (float *)ws : gw;
     // tile-size choice must agree with `tiles` above
-    if (big >= 96 && p.N > 64 && p.M > 64) {
+    const bool use_big = big >= 96 && p.N > 64 && p.M > 64;
+    mrcnn::ProfScope prof(use_big ? mrcnn::PROF_CONV_WGRAD_128 : mrcnn::PROF_CONV_WGRAD_64,
+                          2.0 * p.M * p.N * (double)pixels,
+                          4.0 * ((double)p.M * p.N + (double)pixels * (p.M + (double)C)), s);
+    if (use_big) {
         hipLaunchKernelGGL((conv_gemm_kernel<2, 2, WGRAD>), dim3((unsigned)big, splits), dim3(256), 0,
                            s, p);
     } else {

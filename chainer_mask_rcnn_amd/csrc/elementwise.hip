@@ -354,6 +354,7 @@ extern "C" int mrcnn_sgd_momentum_wd(float *p, const float *g, float *v, int64_t
     if (n == 0) return 0;
     MRCNN_REQUIRE(p && g && v, "sgd: null pointer");
     MRCNN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(v), "sgd: arenas must be 16-byte aligned");
+    mrcnn::ProfScope prof(mrcnn::PROF_SGD, 0., 20.0 * (double)n, mrcnn::as_stream(stream));
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, mrcnn::as_stream(stream),
                        p, g, v, n, lr, momentum, wd, grad_scale);
     return mrcnn::check_launch("sgd");

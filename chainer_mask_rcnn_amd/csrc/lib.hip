@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace mrcnn {
@@ -13,7 +16,98 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- kernel timer -------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t start, stop; int kind; double flops, bytes; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_event_pool;
+hipEvent_t get_event()
+{
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool prof_enabled() { return g_prof_on; }
+
+void prof_begin(int kind, double flops, double bytes, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.start = get_event();
+    r.stop = get_event();
+    r.kind = kind;
+    r.flops = flops;
+    r.bytes = bytes;
+    hipEventRecord(r.start, s);
+    g_prof_recs.push_back(r);
+}
+
+void prof_end(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_recs.empty()) hipEventRecord(g_prof_recs.back().stop, s);
+}
 }  // namespace mrcnn
+
+static const char *kProfNames[mrcnn::PROF_NUM_KINDS] = {
+    "conv_gemm_kernel<2,2,FWD>", "conv_gemm_kernel<1,1,FWD>", "conv_gemm_kernel<2,2,DGRAD>",
+    "conv_gemm_kernel<1,1,DGRAD>", "conv_gemm_kernel<2,2,WGRAD>", "conv_gemm_kernel<1,1,WGRAD>",
+    "roi_align_fwd_kernel", "roi_align_bwd_kernel", "nms_mask_kernel", "nms_scan_kernel",
+    "topk_rank_kernel", "sgd_kernel", "elementwise"};
+
+extern "C" int mrcnn_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(mrcnn::g_prof_mu);
+    for (auto &r : mrcnn::g_prof_recs) {
+        mrcnn::g_event_pool.push_back(r.start);
+        mrcnn::g_event_pool.push_back(r.stop);
+    }
+    mrcnn::g_prof_recs.clear();
+    mrcnn::g_prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int mrcnn_profile_num_kinds(void) { return mrcnn::PROF_NUM_KINDS; }
+
+extern "C" const char *mrcnn_profile_kind_name(int kind)
+{
+    return (kind >= 0 && kind < mrcnn::PROF_NUM_KINDS) ? kProfNames[kind] : "";
+}
+
+// Sums over the launches of `kind` recorded since mrcnn_profile_enable(1).  The caller
+// must have synchronised the stream(s).
+extern "C" int mrcnn_profile_summary(int kind, double *total_ms, double *total_flops,
+                                     double *total_bytes, int64_t *launches)
+{
+    std::lock_guard<std::mutex> lk(mrcnn::g_prof_mu);
+    double ms = 0, fl = 0, by = 0;
+    int64_t n = 0;
+    for (auto &r : mrcnn::g_prof_recs) {
+        if (r.kind != kind) continue;
+        float t = 0.f;
+        hipError_t e = hipEventElapsedTime(&t, r.start, r.stop);
+        if (e != hipSuccess) {
+            mrcnn::set_error("profile_summary: %s", hipGetErrorString(e));
+            return 1;
+        }
+        ms += t; fl += r.flops; by += r.bytes; ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (total_bytes) *total_bytes = by;
+    if (launches) *launches = n;
+    return 0;
+}
 
 extern "C" const char *mrcnn_last_error(void) { return mrcnn::g_err; }
 

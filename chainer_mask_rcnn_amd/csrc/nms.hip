@@ -177,8 +177,13 @@ extern "C" int mrcnn_nms_sorted_batched(const float *bbox, const int32_t *n_dev,
     const int nblk = (n_max + 63) / 64;
     MRCNN_REQUIRE(nblk * 8 <= 64 * 1024, "nms: n_max too large (%d)", n_max);
     MRCNN_REQUIRE(nblk <= 65535 && groups <= 65535, "nms: grid too large");
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, groups), dim3(64), 0, s,
-                       (const float4 *)bbox, n_dev, n_max, nblk, thresh, (uint64_t *)mask_ws);
+    {
+        mrcnn::ProfScope prof(mrcnn::PROF_NMS_MASK, 0.,
+                              (double)groups * n_max * (16.0 + 4.0 * nblk), s);
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, groups), dim3(64), 0, s,
+                           (const float4 *)bbox, n_dev, n_max, nblk, thresh, (uint64_t *)mask_ws);
+    }
+    mrcnn::ProfScope prof(mrcnn::PROF_NMS_SCAN, 0., (double)groups * n_max * 4.0 * nblk, s);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(groups), dim3(256), (size_t)nblk * 8, s,
                        (const uint64_t *)mask_ws, n_dev, n_max, nblk, limit, keep, n_keep);
     return mrcnn::check_launch("nms_sorted");

@@ -159,8 +159,11 @@ extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, 
     const int blocks = (int)mrcnn::ceil_div(n, 256);
     hipLaunchKernelGGL(topk_keys_kernel, dim3(blocks), dim3(256), 0, s, score, valid, n, keys,
                        n_valid);
-    hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks), dim3(256), 0, s, keys, n, k, order, n_valid,
-                       n_out);
+    {
+        mrcnn::ProfScope prof(mrcnn::PROF_TOPK, 0., 12.0 * n, s);
+        hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks), dim3(256), 0, s, keys, n, k, order,
+                           n_valid, n_out);
+    }
     return mrcnn::check_launch("topk_desc");
 }
 

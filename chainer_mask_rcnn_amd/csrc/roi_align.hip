@@ -215,6 +215,9 @@ extern "C" int mrcnn_roi_align_fwd(const float *x, const float *rois, float *y, 
     if (R == 0) return 0;
     const int bins = R * PH * PW;
     hipStream_t s = mrcnn::as_stream(stream);
+    // algorithmic bytes: write R*PH*PW*C, read the feature maps once
+    mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_FWD, 0.,
+                          4.0 * ((double)bins * C + (double)N * H * W * C), s);
     if (C % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0)) {
         const int cv = C / 4;
         hipLaunchKernelGGL(roi_align_fwd_kernel<float4>, dim3(bins), dim3(pick_threads(cv)), 0, s,
@@ -237,6 +240,9 @@ extern "C" int mrcnn_roi_align_bwd(const float *gy, const float *rois, float *gx
     MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * H * W * C, s));
     if (R == 0) return 0;
     const int bins = R * PH * PW;
+    // algorithmic bytes: read R*PH*PW*C, read-modify-write the feature-map gradient
+    mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_BWD, 0.,
+                          4.0 * ((double)bins * C + 2.0 * (double)N * H * W * C), s);
     if (C % 4 == 0 && ((uintptr_t)gx % 16 == 0) && ((uintptr_t)gy % 16 == 0)) {
         const int cv = C / 4;
         hipLaunchKernelGGL(roi_align_bwd_kernel<float4>, dim3(bins), dim3(pick_threads(cv)), 0, s,

@@ -27,6 +27,8 @@ def conv_out_size(size, k, s, p):
 
 def make_desc(x_shape, w_shape, stride, pad):
     N, C, H, W = x_shape
+    if len(w_shape) == 2:            # L.Linear weight (out, in) == 1x1 filter
+        w_shape = (w_shape[0], w_shape[1], 1, 1)
     K, Cw, R, S = w_shape
     if Cw != C:
         raise ValueError('conv: input has %d channels, filter expects %d' % (C, Cw))
@@ -56,7 +58,7 @@ class _Conv2dFn(torch.autograd.Function):
     def forward(ctx, x, W, b, scale, shift, residual, stride, pad, relu):
         _lib.require_device(x, W)
         x = nhwc(x)
-        Wc = nhwc(W)
+        Wc = nhwc(W) if W.dim() == 4 else W.contiguous()
         d = make_desc(x.shape, W.shape, stride, pad)
         flags = 0
         if b is not None:
@@ -100,7 +102,12 @@ class _Conv2dFn(torch.autograd.Function):
         if need_w:
             W = ctx.W_param
             direct = _direct_grad(W)
-            gWt = W.grad if direct else empty_nhwc(tuple(W.shape), gy.device)
+            if direct:
+                gWt = W.grad
+            elif W.dim() == 4:
+                gWt = empty_nhwc(tuple(W.shape), gy.device)
+            else:
+                gWt = torch.empty_like(W)
             ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
                                 gy.device, 'wgrad')
             _lib.call('mrcnn_conv2d_wgrad', ctx_desc(d), _lib.ptr(x), _lib.ptr(g),
@@ -220,5 +227,5 @@ def linear(x, W, b=None):
     """L.Linear: y = x.reshape(N,-1) @ W.T + b, as a 1x1 convolution on (N,C,1,1)."""
     n = x.shape[0]
     x4 = x.reshape(n, -1, 1, 1)
-    y = conv2d(x4, W.reshape(W.shape[0], W.shape[1], 1, 1), b)
+    y = conv2d(x4, W, b)
     return y.reshape(n, W.shape[0])

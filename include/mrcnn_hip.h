@@ -38,6 +38,16 @@ int mrcnn_abi_version(void);
 /* Number of compute units / device name of the current device (diagnostics). */
 int mrcnn_device_info(int *n_cu, char *name, int name_len);
 
+/* Kernel timer: HIP events recorded on the launch stream around every hot kernel while
+ * enabled.  bench.py uses it to report roofline numbers (average launch duration and
+ * algorithmic flops / bytes per kernel kind).  mrcnn_profile_enable(1) clears the
+ * records; mrcnn_profile_summary sums them (synchronise the stream first). */
+int mrcnn_profile_enable(int on);
+int mrcnn_profile_num_kinds(void);
+const char *mrcnn_profile_kind_name(int kind);
+int mrcnn_profile_summary(int kind, double *total_ms, double *total_flops,
+                          double *total_bytes, int64_t *launches);
+
 /* ---- ROIAlign ---------------------------------------------------------- */
 /* Replaces ROIAlign2D.forward_gpu (functions/roi_align_2d.py:162-290).
  * x (N,H,W,C) NHWC, rois (R,5) = (batch, x1, y1, x2, y2), y (R,PH,PW,C). */

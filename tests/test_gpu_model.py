@@ -1,0 +1,179 @@
+"""End-to-end: the assembled HIP model (extractor, RPN, head, losses, backward, SGD) vs a
+plain PyTorch fp32 CPU reference of the same graph with the same weights and the same
+targets, on a tiny image.  Integer outputs (proposals) are compared with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import chainer_mask_rcnn_amd as cmr
+from chainer_mask_rcnn_amd import optimizers
+from oracle import np_ref
+import ref_model
+
+pytestmark = pytest.mark.gpu
+
+H, W = 160, 224
+
+
+def _rel(got, ref):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+@pytest.fixture(scope='module')
+def setup(dev):
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = cmr.models.MaskRCNNResNet(
+        50, n_fg_class=80, anchor_scales=(2, 4, 8, 16, 32), roi_size=14, min_size=H, max_size=W,
+        proposal_creator_params=dict(min_size=0, n_train_pre_nms=600, n_train_post_nms=100,
+                                     n_test_pre_nms=300, n_test_post_nms=50))
+    # make the affine layers non-trivial
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, cmr.links.AffineChannel2D):
+                m.W.uniform_(0.4, 0.9)
+                m.b.normal_(0, 0.1)
+        model.rpn.conv1.b.normal_(0, 0.1)
+        model.head.deconv6.b.normal_(0, 0.1)
+    chain = cmr.models.MaskRCNNTrainChain(
+        model, proposal_target_creator=cmr.models.utils.ProposalTargetCreator(n_sample=32))
+    chain.to(dev).train()
+    rng = np.random.RandomState(0)
+    imgs = rng.uniform(-120, 130, (2, 3, H, W)).astype(np.float32)
+    bboxes = [np.array([[20, 30, 120, 160], [60, 100, 150, 210]], np.float32),
+              np.array([[10, 10, 90, 80]], np.float32)]
+    labels = [np.array([3, 17], np.int32), np.array([42], np.int32)]
+    masks = []
+    for b in bboxes:
+        m = np.zeros((len(b), H, W), np.int32)
+        for g, (y0, x0, y1, x1) in enumerate(b.astype(int)):
+            m[g, y0 + 5:y1 - 5, x0 + 5:x1 - 5] = 1
+        masks.append(m)
+    return model, chain, imgs, bboxes, labels, masks
+
+
+def test_extractor_and_rpn_forward(dev, setup):
+    model, chain, imgs, *_ = setup
+    P = ref_model.RefParams(model)
+    x = torch.tensor(imgs)
+    with torch.no_grad():
+        feat = model.extractor(torch.tensor(imgs, device=dev))
+        feat_ref = ref_model.extractor(x, P)
+        assert tuple(feat.shape) == tuple(feat_ref.shape) == (2, 1024, 11, 15)
+        assert _rel(feat, feat_ref) < 1e-4
+        model.eval()
+        locs, scores, rois, roi_indices, anchor = model.rpn(feat, (H, W), [1., 1.])
+        model.train()
+        locs_ref, scores_ref = ref_model.rpn(feat_ref, P, 15)
+        assert _rel(locs, locs_ref) < 1e-4 and _rel(scores, scores_ref) < 1e-4
+    # proposals: same integer decisions as the oracle's ProposalCreator on the HIP outputs
+    pc = np_ref.ProposalCreator(min_size=0, n_test_pre_nms=300, n_test_post_nms=50)
+    for i in range(2):
+        ref_roi = pc(locs[i].cpu().numpy(), scores[i].cpu().numpy(), anchor.cpu().numpy(),
+                     (H, W), 1., train=False)
+        got = rois[(roi_indices == i)].cpu().numpy()
+        assert got.shape == ref_roi.shape and np.array_equal(got, ref_roi)
+
+
+def test_train_step_matches_reference(dev, setup):
+    model, chain, imgs, bboxes, labels, masks = setup
+    for p in chain.parameters():
+        p.grad = None
+    np.random.seed(123)
+    loss = chain(torch.tensor(imgs, device=dev), bboxes, labels, masks, [1., 1.])
+    loss.backward()
+    rep = {k: float(v) for k, v in chain.report.items()}
+
+    # CPU reference with the same sampled RoIs / targets (replay the RNG stream)
+    P = ref_model.RefParams(model)
+    feat = ref_model.extractor(torch.tensor(imgs), P)
+    rl, rs = ref_model.rpn(feat, P, 15)
+    with torch.no_grad():
+        locs, scores, rois, roi_indices, anchor = model.rpn(
+            model.extractor(torch.tensor(imgs, device=dev)), (H, W), [1., 1.])
+    np.random.seed(123)
+    ptc = chain.proposal_target_creator
+    s_rois, s_idx, g_locs, g_labels, g_masks = [], [], [], [], []
+    rois_h, idx_h = rois.cpu().numpy(), roi_indices.cpu().numpy()
+    for i in range(2):
+        a, b, c, d = ptc(rois_h[idx_h == i], bboxes[i], labels[i], masks[i])
+        s_rois.append(a); s_idx.append(np.full(len(a), i, np.int32))
+        g_locs.append(b); g_labels.append(c); g_masks.append(d)
+    atc = chain.anchor_target_creator
+    r_locs, r_labels = zip(*[atc(b, anchor.cpu().numpy(), (H, W)) for b in bboxes])
+    cat = lambda xs, dt: torch.tensor(np.concatenate(xs, 0), dtype=dt)
+    cls_locs, sc, mk = ref_model.head(feat, cat(s_rois, torch.float32), cat(s_idx, torch.int32),
+                                      P, 81, 14)
+    parts = ref_model.losses(rl, rs, cat(r_locs, torch.float32), cat(r_labels, torch.int32),
+                             cls_locs, sc, mk, cat(g_locs, torch.float32),
+                             cat(g_labels, torch.int32), cat(g_masks, torch.int32))
+    ref_loss = sum(parts)
+    ref_loss.backward()
+    names = ['rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'roi_mask_loss']
+    for n, v in zip(names, parts):
+        assert abs(rep[n] - v.item()) <= 1e-4 * max(abs(v.item()), 1e-3), (n, rep[n], v.item())
+    assert abs(rep['loss'] - ref_loss.item()) <= 1e-4 * abs(ref_loss.item())
+
+    # gradients of every trainable parameter
+    worst = 0.
+    for name, p in model.named_parameters():
+        g_ref = P['' + name].grad
+        if name.startswith('extractor.conv1') or name.startswith('extractor.bn1') \
+                or name.startswith('extractor.res2') or '.bn' in name:
+            continue
+        assert p.grad is not None, name
+        assert g_ref is not None, name
+        r = _rel(p.grad, g_ref)
+        worst = max(worst, r)
+        assert r < 2e-3, (name, r)
+    print('worst relative gradient error', worst)
+
+
+def test_optimizer_arena_step(dev, setup):
+    """MomentumSGD/WeightDecay over the flat arena == per-parameter oracle rule; frozen
+    parameters (conv1, bn1, res2, affine) untouched (examples/train_common.py:176-190)."""
+    model, chain, imgs, bboxes, labels, masks = setup
+    opt = optimizers.MomentumSGD(lr=0.01, momentum=0.9)
+    opt.setup(chain)
+    opt.add_hook(optimizers.WeightDecay(1e-4))
+    optimizers.disable_update(model.extractor.conv1)
+    optimizers.disable_update(model.extractor.bn1)
+    optimizers.disable_update(model.extractor.res2)
+    for m in chain.modules():
+        if isinstance(m, cmr.links.AffineChannel2D):
+            optimizers.disable_update(m)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    np.random.seed(5)
+    opt.update(chain, torch.tensor(imgs, device=dev), bboxes, labels, masks, [1., 1.])
+    opt.update(chain, torch.tensor(imgs, device=dev), bboxes, labels, masks, [1., 1.])
+    torch.cuda.synchronize()
+    n_train = 0
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            assert torch.equal(p, before[n]), n
+        else:
+            n_train += p.numel()
+            assert not torch.equal(p, before[n]), n
+            assert torch.isfinite(p).all()
+    # R-50 trainable parameter count (35.70 M without affine) + fused-head padding
+    assert 35.6e6 < n_train < 35.8e6
+    # second step equals the oracle rule applied to the arena
+    a = opt.arena
+    p0, v0 = a.values.clone(), a.momenta.clone()
+    g = a.grads.clone()
+    opt.step()
+    p_ref, v_ref = np_ref.momentum_sgd_wd(p0.cpu().numpy(), g.cpu().numpy(), v0.cpu().numpy(), 0.01)
+    np.testing.assert_allclose(a.values.cpu().numpy(), p_ref, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(a.momenta.cpu().numpy(), v_ref, rtol=1e-5, atol=1e-7)
+
+
+def test_predict_prepared_runs(dev, setup):
+    model, chain, imgs, *_ = setup
+    bboxes, roi_masks, labels, scores = model.predict_prepared(
+        torch.tensor(imgs, device=dev), [1., 1.], [(H, W), (H, W)])
+    assert len(bboxes) == len(roi_masks) == len(labels) == len(scores) == 2
+    for b, m, l, s in zip(bboxes, roi_masks, labels, scores):
+        assert b.shape[1] == 4 and len(b) == len(m) == len(l) == len(s)
+        assert m.shape[1:] == (80, 14, 14)
+        assert len(b) <= 100
