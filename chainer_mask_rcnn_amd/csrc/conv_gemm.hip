@@ -58,6 +58,13 @@ struct GemmParams {
     int stem;            // FWD: stem gather (8 pixels x 4 ch per K slice)
     int split_len;       // WGRAD: pixels per split
     int64_t split_stride;// WGRAD: floats between split slabs
+    // Fused backward of the producing conv's epilogue, applied while gy is staged
+    // (DGRAD A operand / WGRAD A' operand):  g = gy * (mask_y > 0) * in_scale[k]
+    const float *mask_y;   // output of the ReLU that followed the conv (same shape as gy) or NULL
+    const float *in_scale; // AffineChannel2D scale of that conv (K_out) or NULL
+    // DGRAD epilogue: gx += res_g * (res_y > 0)  (identity-shortcut gradient of a bottleneck)
+    const float *res_g, *res_y;
+    unsigned a_bytes, b_bytes, c_bytes;  // buffer extents (bytes) of A (and mask_y), B, C
 };
 
 template <int TM, int TN, int MODE>
@@ -71,9 +78,41 @@ struct Cfg {
     static constexpr int B_V4 = BN * BK / 4 / 256;
 };
 
-__device__ __forceinline__ float4 ldg4(const float *p, bool ok)
+// ---- buffer addressing -----------------------------------------------------------------
+// Every global access of the kernel goes through a raw buffer descriptor: an element that
+// must read as zero (image border of the im2col gather, tile tails in M / N / K) is given
+// the byte offset kOOB, which lies beyond num_records, so the hardware returns 0 for loads
+// and drops stores.  No per-element branch or select touches a loaded value, so every load
+// of a K slice stays in flight across the slice's MFMAs.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
 {
-    return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? bytes : 0u, 0x00020000);
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                       __uint_as_float(v.w));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, unsigned off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
+}
+__device__ __forceinline__ float4 relu_mask(float4 v, float4 y)
+{
+    return make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f,
+                       y.w > 0.f ? v.w : 0.f);
+}
+__device__ __forceinline__ float4 mul4(float4 v, float4 s)
+{
+    return make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
 }
 
 template <int TM, int TN, int MODE>
@@ -83,45 +122,52 @@ conv_gemm_kernel(const GemmParams p)
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
     constexpr int AV = C_::A_V4, BV = C_::B_V4;
+    constexpr bool HAS_MASK = (MODE != FWD);
     __shared__ __attribute__((aligned(16))) float smem[2][C_::A_FLOATS + C_::B_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // tile -> (m0, n0); blockIdx.x runs along N fastest so that consecutive
-    // blocks share the gathered A rows.
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, p.b_bytes);
+    const __amdgpu_buffer_rsrc_t rMask = make_rsrc(p.mask_y, p.a_bytes);
+    const bool use_mask = HAS_MASK && p.mask_y != nullptr;
+
+    // tile -> (m0, n0).  Workgroup b runs on XCD b % 8 (observed dispatch order); remap so
+    // that each XCD owns a contiguous run of tile ids — N fastest — and neighbouring tiles,
+    // which share the gathered A rows and the filter panel, hit the same private L2.
     const int ntn = (p.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / ntn) * BM;
-    const int n0 = (blockIdx.x % ntn) * BN;
+    int tile = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile / ntn) * BM;
+    const int n0 = (tile % ntn) * BN;
 
     // ---------------- per-thread gather state -----------------------------------
-    // K-contiguous operands: thread covers rows (tid/8 + 32*i), float4 column tid%8.
-    // K-strided operands:    thread covers k rows (tid/(BX/4) + ...), float4 column.
     const int kc_row = tid >> 3, kc_c4 = tid & 7;
-
     int a_n[AV], a_y[AV], a_x[AV];     // FWD/DGRAD: pixel coords of each A row
-    bool a_ok[AV];
     if (MODE != WGRAD) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int m = m0 + kc_row + 32 * i;
-            a_ok[i] = m < p.M;
-            const int mm = a_ok[i] ? m : 0;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
             const int n = mm / (p.gp * p.gq);
             const int rem = mm - n * (p.gp * p.gq);
             const int gy = rem / p.gq, gx = rem - gy * p.gq;
             a_n[i] = n;
             if (MODE == FWD) { a_y[i] = gy * p.stride - p.pad; a_x[i] = gx * p.stride - p.pad; }
             else { a_y[i] = gy + p.pad; a_x[i] = gx + p.pad; }
+            if (!ok) a_y[i] = -(1 << 28);          // row beyond M: every tap out of range
         }
     }
-    // WGRAD: K-strided tiles.  A' = gy^T: k row = tid/(BM/4), col4 = tid%(BM/4).
-    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;            // threads per k row
+    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;            // threads per k row (K-strided tiles)
     constexpr int A_RPP = 256 / A_TPR, B_RPP = 256 / B_TPR;  // k rows per pass
     const int wa_k = tid / A_TPR, wa_c4 = tid % A_TPR;
     const int wb_k = tid / B_TPR, wb_c4 = tid % B_TPR;
-    // WGRAD B' (im2col(x)^T): the thread's column (r,s,c) is fixed; pixels advance.
     int wr = 0, ws_ = 0, wc = 0;
     bool wcol_ok = false;
     int pn[BV], py[BV], px[BV];
@@ -151,29 +197,41 @@ conv_gemm_kernel(const GemmParams p)
     const int nslices = (MODE == WGRAD) ? (k_end - k_begin + BK - 1) / BK : p.R * p.S * cprs;
 
     float4 ra[AV], rb[BV];
+    float4 rm[HAS_MASK ? AV : 1];
+    float4 rscale = make_float4(1.f, 1.f, 1.f, 1.f);
+    const bool use_scale = HAS_MASK && p.in_scale != nullptr;
+    if (MODE == WGRAD && use_scale && m0 + wa_c4 * 4 < p.M)
+        rscale = *reinterpret_cast<const float4 *>(p.in_scale + m0 + wa_c4 * 4);
 
+    // issue the global loads of slice kt (nothing here consumes a loaded value)
     auto load_slice = [&](int kt) {
         if (MODE == FWD || MODE == DGRAD) {
             const int rs = kt / cprs;
             const int c0 = (kt - rs * cprs) * BK;
             const int r = rs / p.S, s = rs - r * p.S;
             const int cc = c0 + kc_c4 * 4;
+            const bool c_ok = p.stem || cc < p.Kc;
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
                 int iy, ix;
                 if (MODE == FWD) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? kc_c4 : 0); }
                 else { iy = a_y[i] - r; ix = a_x[i] - s; }
-                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.sh &&
-                                (unsigned)ix < (unsigned)p.sw && (p.stem || cc < p.Kc);
-                const int off = ((a_n[i] * p.sh + iy) * p.sw + ix) * p.lda + (p.stem ? 0 : cc);
-                ra[i] = ldg4(p.A + off, ok);
+                const bool ok = c_ok && (unsigned)iy < (unsigned)p.sh && (unsigned)ix < (unsigned)p.sw;
+                const unsigned off =
+                    ok ? 4u * (unsigned)(((a_n[i] * p.sh + iy) * p.sw + ix) * p.lda + (p.stem ? 0 : cc))
+                       : kOOB;
+                ra[i] = bload4(rA, off);
+                if (MODE == DGRAD && use_mask) rm[i] = bload4(rMask, off);
             }
+            if (MODE == DGRAD && use_scale)
+                rscale = cc < p.Kc ? *reinterpret_cast<const float4 *>(p.in_scale + cc)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == FWD) {
 #pragma unroll
                 for (int i = 0; i < BV; ++i) {
                     const int n = n0 + kc_row + 32 * i;
                     const bool ok = n < p.N && cc < p.Kc;
-                    rb[i] = ldg4(p.B + (int64_t)n * p.ldb + rs * p.Kc + cc, ok);
+                    rb[i] = bload4(rB, ok ? 4u * (unsigned)(n * p.ldb + rs * p.Kc + cc) : kOOB);
                 }
             } else {
 #pragma unroll
@@ -181,7 +239,7 @@ conv_gemm_kernel(const GemmParams p)
                     const int k = c0 + wb_k + B_RPP * i;
                     const int n = n0 + wb_c4 * 4;
                     const bool ok = k < p.Kc && n < p.N;
-                    rb[i] = ldg4(p.B + (int64_t)k * p.ldb + rs * p.cin + n, ok);
+                    rb[i] = bload4(rB, ok ? 4u * (unsigned)(k * p.ldb + rs * p.cin + n) : kOOB);
                 }
             }
         } else {
@@ -190,7 +248,10 @@ conv_gemm_kernel(const GemmParams p)
             for (int i = 0; i < AV; ++i) {
                 const int m = kb + wa_k + A_RPP * i;
                 const int k = m0 + wa_c4 * 4;
-                ra[i] = ldg4(p.A + (int64_t)m * p.ldg + k, m < k_end && k < p.M);
+                const bool ok = m < k_end && k < p.M;
+                const unsigned off = ok ? 4u * (unsigned)(m * p.ldg + k) : kOOB;
+                ra[i] = bload4(rA, off);
+                if (use_mask) rm[i] = bload4(rMask, off);
             }
 #pragma unroll
             for (int i = 0; i < BV; ++i) {
@@ -199,8 +260,8 @@ conv_gemm_kernel(const GemmParams p)
                 const int ix = px[i] * p.stride - p.pad + ws_;
                 const bool ok = wcol_ok && m < k_end && (unsigned)iy < (unsigned)p.sh &&
                                 (unsigned)ix < (unsigned)p.sw;
-                const int off = ((pn[i] * p.sh + iy) * p.sw + ix) * p.lda + wc;
-                rb[i] = ldg4(p.B + off, ok);
+                rb[i] = bload4(rB, ok ? 4u * (unsigned)(((pn[i] * p.sh + iy) * p.sw + ix) * p.lda + wc)
+                                      : kOOB);
                 // advance this row's pixel by BK for the next slice
                 if (p.gp * p.gq == 1) {
                     pn[i] += BK;
@@ -215,17 +276,19 @@ conv_gemm_kernel(const GemmParams p)
         }
     };
 
+    // registers -> LDS; the fused epilogue-backward (ReLU mask, affine scale) is applied here
     auto store_slice = [&](int buf) {
         float *sa = smem[buf];
         float *sb = smem[buf] + C_::A_FLOATS;
-        if (C_::A_KC) {
 #pragma unroll
-            for (int i = 0; i < AV; ++i)
-                *reinterpret_cast<float4 *>(sa + (kc_row + 32 * i) * (BK + KPAD) + kc_c4 * 4) = ra[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < AV; ++i)
-                *reinterpret_cast<float4 *>(sa + (wa_k + A_RPP * i) * BM + wa_c4 * 4) = ra[i];
+        for (int i = 0; i < AV; ++i) {
+            float4 v = ra[i];
+            if (HAS_MASK && use_mask) v = relu_mask(v, rm[i]);
+            if (HAS_MASK && use_scale) v = mul4(v, rscale);
+            if (C_::A_KC)
+                *reinterpret_cast<float4 *>(sa + (kc_row + 32 * i) * (BK + KPAD) + kc_c4 * 4) = v;
+            else
+                *reinterpret_cast<float4 *>(sa + (wa_k + A_RPP * i) * BM + wa_c4 * 4) = v;
         }
         if (C_::B_KC) {
 #pragma unroll
@@ -303,52 +366,85 @@ conv_gemm_kernel(const GemmParams p)
     }
 
     // ---------------- epilogue ------------------------------------------------------
-    float *out = p.C;
-    if (MODE == WGRAD) out += (int64_t)blockIdx.y * p.split_stride;
+    // Per 32x32 MFMA tile: compute the 16 element offsets, issue every auxiliary load
+    // (residual / accumulate / shortcut gradient) back to back, then combine and store.
+    const float *out_base = p.C;
+    if (MODE == WGRAD) out_base += (int64_t)blockIdx.y * p.split_stride;
+    const __amdgpu_buffer_rsrc_t rC = make_rsrc(out_base, p.c_bytes);
+    const __amdgpu_buffer_rsrc_t rRes = make_rsrc(p.residual, p.c_bytes);
+    const __amdgpu_buffer_rsrc_t rResG = make_rsrc(p.res_g, p.c_bytes);
+    const __amdgpu_buffer_rsrc_t rResY = make_rsrc(p.res_y, p.c_bytes);
+    const bool f_bias = (p.flags & MRCNN_EPI_BIAS) != 0, f_aff = (p.flags & MRCNN_EPI_AFFINE) != 0;
+    const bool f_res = (p.flags & MRCNN_EPI_RESIDUAL) != 0, f_relu = (p.flags & MRCNN_EPI_RELU) != 0;
+    const bool f_acc = (p.flags & MRCNN_EPI_ACCUM) != 0;
+    const bool f_resg = MODE == DGRAD && p.res_g != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (32 * TN) + j * 32 + li;
-        if (col >= p.N) continue;
+        const bool col_ok = col < p.N;
+        const int colc = col_ok ? col : 0;
         float bias = 0.f, scale = 1.f, shift = 0.f;
-        if (MODE == FWD || MODE == DGRAD) {
-            if (p.flags & MRCNN_EPI_BIAS) bias = p.bias[p.out_mode == OUT_DECONV ? col % p.ko : col];
-            if (p.flags & MRCNN_EPI_AFFINE) { scale = p.scale[col]; shift = p.shift[col]; }
+        if (MODE != WGRAD) {
+            if (f_bias) bias = p.bias[p.out_mode == OUT_DECONV ? colc % p.ko : colc];
+            if (f_aff) { scale = p.scale[colc]; shift = p.shift[colc]; }
         }
-        int64_t col_off = col;
+        int col_off = colc;
         if (MODE == DGRAD && p.out_mode == OUT_DECONV) {
-            const int ab = col / p.ko, o = col - ab * p.ko;
-            const int a = ab >> 1, b = ab & 1;
-            col_off = ((int64_t)a * (2 * p.gq) + b) * p.ko + o;
+            const int ab = colc / p.ko, o = colc - ab * p.ko;
+            col_off = ((ab >> 1) * (2 * p.gq) + (ab & 1)) * p.ko + o;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (row >= p.M) continue;
-                int64_t off;
-                if (MODE == DGRAD && p.out_mode == OUT_STRIDED) {
-                    const int n = row / (p.gp * p.gq);
-                    const int rem = row - n * (p.gp * p.gq);
-                    const int gy = rem / p.gq, gx = rem - gy * p.gq;
-                    off = (((int64_t)n * p.oh + gy * p.stride) * p.ow + gx * p.stride) * p.ldc + col_off;
-                } else if (MODE == DGRAD && p.out_mode == OUT_DECONV) {
-                    const int n = row / (p.gp * p.gq);
-                    const int rem = row - n * (p.gp * p.gq);
-                    const int gy = rem / p.gq, gx = rem - gy * p.gq;
-                    off = (((int64_t)n * (2 * p.gp) + 2 * gy) * (2 * p.gq) + 2 * gx) * p.ko + col_off;
-                } else {
-                    off = (int64_t)row * p.ldc + col_off;
+            for (int g = 0; g < 2; ++g) {        // two groups of 8 accumulator rows
+                unsigned off[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = g * 8 + q;
+                    const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                    int o;
+                    if (MODE == DGRAD && p.out_mode != OUT_PLAIN) {
+                        const int rr = row < p.M ? row : 0;
+                        const int n = rr / (p.gp * p.gq);
+                        const int rem = rr - n * (p.gp * p.gq);
+                        const int gy = rem / p.gq, gx = rem - gy * p.gq;
+                        if (p.out_mode == OUT_STRIDED)
+                            o = ((n * p.oh + gy * p.stride) * p.ow + gx * p.stride) * p.ldc + col_off;
+                        else
+                            o = ((n * (2 * p.gp) + 2 * gy) * (2 * p.gq) + 2 * gx) * p.ko + col_off;
+                    } else {
+                        o = row * p.ldc + col_off;
+                    }
+                    off[q] = (col_ok && row < p.M) ? 4u * (unsigned)o : kOOB;
                 }
-                float v = acc[i][j][e];
+                float aux0[8], aux1[8], aux2[8];
                 if (MODE != WGRAD) {
-                    if (p.flags & MRCNN_EPI_BIAS) v += bias;
-                    if (p.flags & MRCNN_EPI_AFFINE) v = v * scale + shift;
-                    if (p.flags & MRCNN_EPI_RESIDUAL) v += p.residual[off];
-                    if (p.flags & MRCNN_EPI_ACCUM) v += out[off];
-                    if (p.flags & MRCNN_EPI_RELU) v = fmaxf(v, 0.f);
+                    if (f_res) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) aux0[q] = bload1(rRes, off[q]);
+                    }
+                    if (f_acc) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) aux1[q] = bload1(rC, off[q]);
+                    }
+                    if (f_resg) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { aux0[q] = bload1(rResG, off[q]); aux2[q] = bload1(rResY, off[q]); }
+                    }
                 }
-                out[off] = v;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = acc[i][j][g * 8 + q];
+                    if (MODE != WGRAD) {
+                        if (f_bias) v += bias;
+                        if (f_aff) v = v * scale + shift;
+                        if (f_res) v += aux0[q];
+                        if (f_acc) v += aux1[q];
+                        if (f_resg) v += aux2[q] > 0.f ? aux0[q] : 0.f;
+                        if (f_relu) v = fmaxf(v, 0.f);
+                    }
+                    bstore1(rC, off[q], v);
+                }
             }
         }
     }
@@ -412,6 +508,19 @@ int check_desc(const mrcnn_conv_desc *d)
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p % 16) == 0; }
 
+// buffer extents in floats -> bytes; 32-bit buffer offsets need every tensor < 2 GiB
+int set_extents(GemmParams &p, int64_t a_floats, int64_t b_floats, int64_t c_floats)
+{
+    const int64_t lim = (int64_t)1 << 29;
+    MRCNN_REQUIRE(a_floats < lim && b_floats < lim && c_floats < lim,
+                  "conv: a tensor exceeds 2 GiB (%lld / %lld / %lld floats); split the batch",
+                  (long long)a_floats, (long long)b_floats, (long long)c_floats);
+    p.a_bytes = (unsigned)(a_floats * 4);
+    p.b_bytes = (unsigned)(b_floats * 4);
+    p.c_bytes = (unsigned)(c_floats * 4);
+    return 0;
+}
+
 int wgrad_splits(int64_t tiles, int64_t pixels)
 {
     // enough workgroups to fill 256 CUs ~3x, each split at least 8 K slices deep
@@ -441,6 +550,9 @@ extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const 
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
     p.lda = d->C; p.ldb = d->R * d->S * d->C; p.ldc = d->K;
     p.flags = epi_flags; p.out_mode = OUT_PLAIN;
+    if (int rc = set_extents(p, (int64_t)d->N * d->H * d->W * d->C, (int64_t)d->K * d->R * d->S * d->C,
+                             (int64_t)d->N * d->P * d->Q * d->K))
+        return rc;
     return launch<FWD>(p, 1, mrcnn::as_stream(stream));
 }
 
@@ -462,23 +574,45 @@ extern "C" int mrcnn_conv_stem_fwd(const float *x4, const float *w784, const flo
     p.R = 7; p.S = 1; p.stride = 2; p.pad = 3;
     p.lda = 4; p.ldb = 7 * 32; p.ldc = K;
     p.flags = epi_flags; p.out_mode = OUT_PLAIN; p.stem = 1;
+    if (int rc = set_extents(p, (int64_t)N * H * W * 4, (int64_t)K * 7 * 32, (int64_t)N * P * Q * K))
+        return rc;
     return launch<FWD>(p, 1, mrcnn::as_stream(stream));
 }
+
+extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, const float *w,
+                                     float *gx, int epi_flags, const float *mask_y,
+                                     const float *in_scale, const float *res_g,
+                                     const float *res_y, void *stream);
 
 extern "C" int mrcnn_conv2d_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w,
                                   float *gx, int epi_flags, void *stream)
 {
+    return mrcnn_conv2d_dgrad_ex(d, gy, w, gx, epi_flags, nullptr, nullptr, nullptr, nullptr,
+                                 stream);
+}
+
+extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, const float *w,
+                                     float *gx, int epi_flags, const float *mask_y,
+                                     const float *in_scale, const float *res_g,
+                                     const float *res_y, void *stream)
+{
     if (int rc = check_desc(d)) return rc;
+    MRCNN_REQUIRE((res_g == nullptr) == (res_y == nullptr), "conv2d_dgrad: res_g/res_y go together");
+    MRCNN_REQUIRE(!res_g || d->stride == 1, "conv2d_dgrad: residual gradient needs stride 1");
     MRCNN_REQUIRE(gy && w && gx, "conv2d_dgrad: null pointer");
     MRCNN_REQUIRE(aligned16(gy) && aligned16(w), "conv2d_dgrad: gy/w must be 16-byte aligned");
     MRCNN_REQUIRE((epi_flags & ~MRCNN_EPI_ACCUM) == 0, "conv2d_dgrad: only MRCNN_EPI_ACCUM is valid");
     hipStream_t s = mrcnn::as_stream(stream);
     GemmParams p = {};
     p.A = gy; p.B = w; p.C = gx;
+    p.mask_y = mask_y; p.in_scale = in_scale; p.res_g = res_g; p.res_y = res_y;
     p.N = d->C; p.Kc = d->K; p.cin = d->C;
     p.R = d->R; p.S = d->S; p.pad = d->pad;
     p.lda = d->K; p.ldb = d->R * d->S * d->C; p.ldc = d->C;
     p.flags = epi_flags;
+    if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->R * d->S * d->C,
+                             (int64_t)d->N * d->H * d->W * d->C))
+        return rc;
     p.sh = d->P; p.sw = d->Q;
     if (d->stride == 1) {
         p.M = d->N * d->H * d->W; p.gp = d->H; p.gq = d->W; p.stride = 1;
@@ -504,10 +638,12 @@ extern "C" int64_t mrcnn_conv2d_wgrad_workspace_bytes(const mrcnn_conv_desc *d)
 
 static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int Kout, int64_t pixels,
                       int N_, int H, int W, int C, int P, int Q, int R, int S, int stride, int pad,
-                      void *ws, hipStream_t s)
+                      void *ws, hipStream_t s, const float *mask_y = nullptr,
+                      const float *in_scale = nullptr)
 {
     GemmParams p = {};
     p.A = gy; p.B = x;
+    p.mask_y = mask_y; p.in_scale = in_scale;
     p.M = Kout; p.N = R * S * C; p.Kc = (int)pixels;
     p.gp = P; p.gq = Q; p.sh = H; p.sw = W;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad;
@@ -522,6 +658,7 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     p.split_len = (int)(mrcnn::ceil_div(mrcnn::ceil_div(pixels, splits), BK) * BK);
     splits = (int)mrcnn::ceil_div(pixels, p.split_len);
     p.split_stride = gwsz;
+    if (int rc = set_extents(p, pixels * ldg, (int64_t)N_ * H * W * C, gwsz)) return rc;
     p.C = splits > 1 ? (float *)ws : gw;
     // tile-size choice must agree with `tiles` above
     const bool use_big = big >= 96 && p.N > 64 && p.M > 64;
@@ -544,15 +681,23 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     return mrcnn::check_launch("conv_wgrad");
 }
 
-extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc *d, const float *x, const float *gy,
-                                  float *gw, void *ws, void *stream)
+extern "C" int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float *gy,
+                                     float *gw, void *ws, const float *mask_y,
+                                     const float *in_scale, void *stream)
 {
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(x && gy && gw, "conv2d_wgrad: null pointer");
     MRCNN_REQUIRE(aligned16(x) && aligned16(gy) && aligned16(gw) && (!ws || aligned16(ws)),
                   "conv2d_wgrad: pointers must be 16-byte aligned");
     return wgrad_impl(gy, d->K, x, gw, d->K, (int64_t)d->N * d->P * d->Q, d->N, d->H, d->W, d->C,
-                      d->P, d->Q, d->R, d->S, d->stride, d->pad, ws, mrcnn::as_stream(stream));
+                      d->P, d->Q, d->R, d->S, d->stride, d->pad, ws, mrcnn::as_stream(stream),
+                      mask_y, in_scale);
+}
+
+extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc *d, const float *x, const float *gy,
+                                  float *gw, void *ws, void *stream)
+{
+    return mrcnn_conv2d_wgrad_ex(d, x, gy, gw, ws, nullptr, nullptr, stream);
 }
 
 // ---- Deconvolution 2x2 stride 2 (= adjoint of a 2x2/2 convolution g: (N,2H,2W,K) -> (N,H,W,C)
@@ -574,6 +719,8 @@ extern "C" int mrcnn_deconv2x2s2_fwd(const float *x, const float *w, const float
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.lda = C; p.ldb = 4 * K; p.ldc = K;
     p.flags = epi_flags; p.out_mode = OUT_DECONV; p.ko = K;
+    if (int rc = set_extents(p, (int64_t)N * H * W * C, (int64_t)C * 4 * K, (int64_t)N * 4 * H * W * K))
+        return rc;
     return launch<DGRAD>(p, 1, mrcnn::as_stream(stream));
 }
 

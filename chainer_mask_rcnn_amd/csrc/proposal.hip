@@ -9,6 +9,8 @@
 //
 // Built with -ffp-contract=off: the box arithmetic is the same sequence of
 // separately rounded fp32 operations NumPy performs.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -65,22 +67,36 @@ __global__ void topk_keys_kernel(const float *__restrict__ score,
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, (int)__popcll(b));
 }
 
-// rank[i] = #{j : key_j > key_i}; keys are read with wave-uniform (scalar) loads.
+// rank[i] = #{j : key_j > key_i}.  Grid (i-blocks, j-splits): every workgroup counts its
+// 256 keys against one slice of the key array (read with wave-uniform scalar loads, 32 keys
+// in flight) and adds the partial count to rank[i]; the j-split multiplies the number of
+// resident waves so the scalar-load latency is hidden.
 __global__ void __launch_bounds__(256)
-topk_rank_kernel(const uint64_t *__restrict__ keys, int n, int k, int32_t *__restrict__ order,
-                 const int32_t *__restrict__ n_valid, int32_t *__restrict__ n_out)
+topk_rank_kernel(const uint64_t *__restrict__ keys, int n, int chunk, int32_t *__restrict__ rank)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = min(k, *n_valid);
     const uint64_t ki = i < n ? keys[i] : ~0ull;
+    const int j0 = blockIdx.y * chunk;
+    const int j1 = min(n, j0 + chunk);
     int cnt = 0;
-    int j = 0;
-    for (; j + 8 <= n; j += 8) {
+    int j = j0;
+    for (; j + 32 <= j1; j += 32) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cnt += keys[j + u] > ki;
+        for (int u = 0; u < 32; ++u) cnt += keys[j + u] > ki;
     }
-    for (; j < n; ++j) cnt += keys[j] > ki;
-    if (i < n && ki != 0ull && cnt < k) order[cnt] = i;
+    for (; j < j1; ++j) cnt += keys[j] > ki;
+    if (i < n && cnt) atomicAdd(&rank[i], cnt);
+}
+
+__global__ void topk_scatter_kernel(const uint64_t *__restrict__ keys,
+                                    const int32_t *__restrict__ rank, int n, int k,
+                                    int32_t *__restrict__ order,
+                                    const int32_t *__restrict__ n_valid,
+                                    int32_t *__restrict__ n_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *n_out = min(k, *n_valid);
+    if (i < n && keys[i] != 0ull && rank[i] < k) order[rank[i]] = i;
 }
 
 __global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx,
@@ -141,7 +157,7 @@ extern "C" int mrcnn_decode_clip(const float *anchor, const float *loc, float *r
     return mrcnn::check_launch("decode_clip");
 }
 
-extern "C" int64_t mrcnn_topk_workspace_bytes(int n) { return (int64_t)n * 8 + 64; }
+extern "C" int64_t mrcnn_topk_workspace_bytes(int n) { return (int64_t)n * 12 + 128; }
 
 extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, int k,
                                int32_t *order, int32_t *n_out, void *ws, void *stream)
@@ -153,17 +169,25 @@ extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, 
         if (n_out) MRCNN_HIP_TRY(hipMemsetAsync(n_out, 0, 4, s));
         return 0;
     }
+    // workspace: [n_valid | pad to 64 B][rank n x i32][pad][keys n x u64]
     int32_t *n_valid = (int32_t *)ws;
-    uint64_t *keys = (uint64_t *)((char *)ws + 64);
-    MRCNN_HIP_TRY(hipMemsetAsync(n_valid, 0, 4, s));
+    int32_t *rank = (int32_t *)((char *)ws + 64);
+    const size_t keys_off = 64 + (((size_t)n * 4 + 63) / 64) * 64;
+    uint64_t *keys = (uint64_t *)((char *)ws + keys_off);
+    MRCNN_HIP_TRY(hipMemsetAsync(ws, 0, keys_off, s));
     const int blocks = (int)mrcnn::ceil_div(n, 256);
     hipLaunchKernelGGL(topk_keys_kernel, dim3(blocks), dim3(256), 0, s, score, valid, n, keys,
                        n_valid);
+    int splits = (int)std::min<int64_t>(32, std::max<int64_t>(1, 4096 / blocks));
+    const int chunk = (int)(mrcnn::ceil_div(mrcnn::ceil_div(n, splits), 32) * 32);
+    splits = (int)mrcnn::ceil_div(n, chunk);
     {
         mrcnn::ProfScope prof(mrcnn::PROF_TOPK, 0., 12.0 * n, s);
-        hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks), dim3(256), 0, s, keys, n, k, order,
-                           n_valid, n_out);
+        hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks, splits), dim3(256), 0, s, keys, n, chunk,
+                           rank);
     }
+    hipLaunchKernelGGL(topk_scatter_kernel, dim3(blocks), dim3(256), 0, s, keys, rank, n, k, order,
+                       n_valid, n_out);
     return mrcnn::check_launch("topk_desc");
 }
 

@@ -145,6 +145,11 @@ __device__ __forceinline__ void atomic_add_vec(float4 *p, float4 v)
     unsafeAtomicAdd(q + 2, v.z);
     unsafeAtomicAdd(q + 3, v.w);
 }
+__device__ __forceinline__ float vfma(float acc, float w, float v) { return acc + w * v; }
+__device__ __forceinline__ float4 vfma(float4 acc, float w, float4 v)
+{
+    return make_float4(acc.x + w * v.x, acc.y + w * v.y, acc.z + w * v.z, acc.w + w * v.w);
+}
 __device__ __forceinline__ float scale_div(float d, float w, float c) { return d * w / c; }
 __device__ __forceinline__ float4 scale_div(float4 d, float w, float c)
 {
@@ -183,6 +188,101 @@ __global__ void roi_align_bwd_kernel(const V *__restrict__ gy, const float *__re
                 atomic_add_vec(&img[((int64_t)ty.hi * W + tx.lo) * CV + c], scale_div(d, w3, g.count));
                 atomic_add_vec(&img[((int64_t)ty.hi * W + tx.hi) * CV + c], scale_div(d, w4, g.count));
             }
+        }
+    }
+}
+
+// ---- gather-form backward ------------------------------------------------------------
+// The scatter form above issues 4*grid_h*grid_w float atomics per output element
+// (~2e9 at the C2 shape: atomic-rate bound, 13 ms).  Bilinear weights are separable,
+//   w(sample -> pixel (y,x)) = wy(y; sample row) * wx(x; sample col),
+// so the gradient a RoI sends to pixel (y,x) is
+//   sum_ph sum_pw  Ay[y][ph] * Bx[x][pw] * gy[roi, ph, pw, :] / count,
+// with Ay[y][ph] = sum over the bin's valid sample rows of their weight on row y (and Bx
+// likewise).  One workgroup owns one (roi, feature row y): it builds Ay (PH floats) and
+// Bx (patch width x PW floats) in LDS, then every lane (a float4 of channels) gathers the
+// <= 3x3 contributing bins per pixel with coalesced reads and issues ONE atomic add per
+// (pixel, channel) — the RoI's patch area instead of 4x its sample count.
+template <typename V>
+__global__ void __launch_bounds__(256)
+roi_align_bwd_gather_kernel(const V *__restrict__ gy, const float *__restrict__ rois,
+                            V *__restrict__ gx, int H, int W, int CV, int PH, int PW,
+                            float spatial_scale, int sampling_ratio)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n = blockIdx.y;
+    const RoiGeom g = roi_geom(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio);
+
+    // rows/cols any sample of this RoI can touch
+    const float y_first = g.start_h + .5f * g.bin_h / (float)g.grid_h;
+    const float y_last = g.start_h + (PH - 1) * g.bin_h + (g.grid_h - .5f) * g.bin_h / (float)g.grid_h;
+    const float x_first = g.start_w + .5f * g.bin_w / (float)g.grid_w;
+    const float x_last = g.start_w + (PW - 1) * g.bin_w + (g.grid_w - .5f) * g.bin_w / (float)g.grid_w;
+    const int ylo = max(0, min(H - 1, (int)floorf(fmaxf(y_first, 0.f)) - 1));
+    const int yhi = max(0, min(H - 1, (int)floorf(fmaxf(y_last, 0.f)) + 2));
+    const int xlo = max(0, min(W - 1, (int)floorf(fmaxf(x_first, 0.f)) - 1));
+    const int xhi = max(0, min(W - 1, (int)floorf(fmaxf(x_last, 0.f)) + 2));
+    const int y = ylo + blockIdx.x;
+    if (y > yhi) return;
+    const int PX = xhi - xlo + 1;
+
+    float *Ay = lds;                       // [PH]
+    float *Bx = lds + PH;                  // [PX][PW]
+    int *pwlo = reinterpret_cast<int *>(Bx + (W + 4) * PW);  // [PX]
+    int *pwhi = pwlo + (W + 4);
+    for (int ph = threadIdx.x; ph < PH; ph += blockDim.x) {
+        float a = 0.f;
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float yy = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
+            const Tap1D t = tap1d(yy, H);
+            if (!t.valid) continue;
+            if (t.lo == y) a += t.h;
+            if (t.hi == y) a += t.l;
+        }
+        Ay[ph] = a;
+    }
+    for (int e = threadIdx.x; e < PX * PW; e += blockDim.x) {
+        const int xi = e / PW, pw = e - xi * PW;
+        const int x = xlo + xi;
+        float b = 0.f;
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+            const float xx = g.start_w + pw * g.bin_w + (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
+            const Tap1D t = tap1d(xx, W);
+            if (!t.valid) continue;
+            if (t.lo == x) b += t.h;
+            if (t.hi == x) b += t.l;
+        }
+        Bx[e] = b;
+    }
+    __syncthreads();
+    for (int xi = threadIdx.x; xi < PX; xi += blockDim.x) {
+        int lo = PW, hi = -1;
+        for (int pw = 0; pw < PW; ++pw)
+            if (Bx[xi * PW + pw] != 0.f) { lo = min(lo, pw); hi = pw; }
+        pwlo[xi] = lo;
+        pwhi[xi] = hi;
+    }
+    __syncthreads();
+    int phlo = PH, phhi = -1;
+    for (int ph = 0; ph < PH; ++ph)
+        if (Ay[ph] != 0.f) { phlo = min(phlo, ph); phhi = ph; }
+    if (phhi < 0) return;
+
+    const float inv_count = 1.f / g.count;
+    const V *__restrict__ top = gy + (int64_t)n * PH * PW * CV;
+    V *__restrict__ row = gx + (((int64_t)g.batch * H + y) * W + xlo) * CV;
+    for (int c = threadIdx.x; c < CV; c += blockDim.x) {
+        for (int xi = 0; xi < PX; ++xi) {
+            const int l = pwlo[xi], h = pwhi[xi];
+            if (h < 0) continue;
+            V acc = VecOps<V>::zero();
+            for (int ph = phlo; ph <= phhi; ++ph) {
+                const float ay = Ay[ph] * inv_count;
+                if (ay == 0.f) continue;
+                for (int pw = l; pw <= h; ++pw)
+                    acc = vfma(acc, ay * Bx[xi * PW + pw], top[((int64_t)ph * PW + pw) * CV + c]);
+            }
+            atomic_add_vec(&row[(int64_t)xi * CV + c], acc);
         }
     }
 }
@@ -243,11 +343,21 @@ extern "C" int mrcnn_roi_align_bwd(const float *gy, const float *rois, float *gx
     // algorithmic bytes: read R*PH*PW*C, read-modify-write the feature-map gradient
     mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_BWD, 0.,
                           4.0 * ((double)bins * C + 2.0 * (double)N * H * W * C), s);
-    if (C % 4 == 0 && ((uintptr_t)gx % 16 == 0) && ((uintptr_t)gy % 16 == 0)) {
-        const int cv = C / 4;
-        hipLaunchKernelGGL(roi_align_bwd_kernel<float4>, dim3(bins), dim3(pick_threads(cv)), 0, s,
-                           (const float4 *)gy, rois, (float4 *)gx, H, W, cv, PH, PW, spatial_scale,
-                           sampling_ratio);
+    const bool vec = C % 4 == 0 && ((uintptr_t)gx % 16 == 0) && ((uintptr_t)gy % 16 == 0);
+    const size_t lds = sizeof(float) * ((size_t)PH + (size_t)(W + 4) * PW) + sizeof(int) * 2 * (W + 4);
+    if (lds <= 48 * 1024 && H <= 65535 && R <= 65535) {
+        // gather form: one workgroup per (roi, feature row), one atomic per (pixel, channel)
+        if (vec)
+            hipLaunchKernelGGL(roi_align_bwd_gather_kernel<float4>, dim3(H, R),
+                               dim3(pick_threads(C / 4)), lds, s, (const float4 *)gy, rois,
+                               (float4 *)gx, H, W, C / 4, PH, PW, spatial_scale, sampling_ratio);
+        else
+            hipLaunchKernelGGL(roi_align_bwd_gather_kernel<float>, dim3(H, R), dim3(pick_threads(C)),
+                               lds, s, gy, rois, gx, H, W, C, PH, PW, spatial_scale, sampling_ratio);
+    } else if (vec) {
+        hipLaunchKernelGGL(roi_align_bwd_kernel<float4>, dim3(bins), dim3(pick_threads(C / 4)), 0, s,
+                           (const float4 *)gy, rois, (float4 *)gx, H, W, C / 4, PH, PW,
+                           spatial_scale, sampling_ratio);
     } else {
         hipLaunchKernelGGL(roi_align_bwd_kernel<float>, dim3(bins), dim3(pick_threads(C)), 0, s, gy,
                            rois, gx, H, W, C, PH, PW, spatial_scale, sampling_ratio);

@@ -229,3 +229,100 @@ def linear(x, W, b=None):
     x4 = x.reshape(n, -1, 1, 1)
     y = conv2d(x4, W, b)
     return y.reshape(n, W.shape[0])
+
+
+# ---------------------------------------------------------------------------------------
+# Whole-bottleneck op: chainer BottleneckA / BottleneckB as ONE autograd
+# node.  Forward = 3 (4) fused implicit-GEMM launches; backward = 3 (4) dgrad + 3 (4) wgrad
+# launches and NOTHING else: the ReLU masks and affine scales are applied while the
+# incoming gradient is staged into LDS, and the identity-shortcut gradient is added in the
+# dgrad epilogue, so there is no elementwise pass and no gradient-accumulation kernel.
+# ---------------------------------------------------------------------------------------
+
+def _fwd_raw(x, Wc, d, scale, shift, residual, relu):
+    flags = (EPI_AFFINE if scale is not None else 0) | (EPI_RESIDUAL if residual is not None else 0) \
+        | (EPI_RELU if relu else 0)
+    y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
+    _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), None, _lib.ptr(scale),
+              _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(y), flags, _lib.stream_ptr())
+    return y
+
+
+def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, accum=False):
+    gx = out if out is not None else empty_nhwc((d.N, d.C, d.H, d.W), g.device)
+    _lib.call('mrcnn_conv2d_dgrad_ex', ctx_desc(d), _lib.ptr(g), _lib.ptr(Wc), _lib.ptr(gx),
+              EPI_ACCUM if accum else 0, _lib.ptr(mask_y), _lib.ptr(in_scale), _lib.ptr(res_g),
+              _lib.ptr(res_y), _lib.stream_ptr())
+    return gx
+
+
+def _wgrad_raw(d, x, g, W, mask_y, in_scale):
+    """Returns the tensor autograd should see for W (None when written in place)."""
+    direct = _direct_grad(W)
+    gW = W.grad if direct else empty_nhwc(tuple(W.shape), g.device)
+    ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
+                        g.device, 'wgrad')
+    _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(g), _lib.ptr(gW),
+              _lib.ptr(ws), _lib.ptr(mask_y), _lib.ptr(in_scale), _lib.stream_ptr())
+    return None if direct else gW
+
+
+class _BottleneckFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, W1, s1, b1, W2, s2, b2, W3, s3, b3, W4, s4, b4, stride):
+        _lib.require_device(x, W1)
+        x = nhwc(x)
+        d1 = make_desc(x.shape, W1.shape, stride, 0)
+        h1 = _fwd_raw(x, nhwc(W1), d1, s1, b1, None, True)
+        d2 = make_desc(h1.shape, W2.shape, 1, 1)
+        h2 = _fwd_raw(h1, nhwc(W2), d2, s2, b2, None, True)
+        d4 = None
+        if W4 is not None:
+            d4 = make_desc(x.shape, W4.shape, stride, 0)
+            shortcut = _fwd_raw(x, nhwc(W4), d4, s4, b4, None, False)
+        else:
+            shortcut = x
+        d3 = make_desc(h2.shape, W3.shape, 1, 0)
+        y = _fwd_raw(h2, nhwc(W3), d3, s3, b3, shortcut, True)
+        ctx.descs = (d1, d2, d3, d4)
+        ctx.params = (W1, W2, W3, W4)
+        ctx.save_for_backward(x, h1, h2, y, s1, s2, s3, s4)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, h1, h2, y, s1, s2, s3, s4 = ctx.saved_tensors
+        d1, d2, d3, d4 = ctx.descs
+        W1, W2, W3, W4 = ctx.params
+        gy = nhwc(gy)
+        ng = ctx.needs_input_grad
+        gW1 = gW2 = gW3 = gW4 = gx = None
+        # conv3 <- relu/affine(bn3) of the block output
+        gh2 = _dgrad_raw(d3, gy, nhwc(W3), y, s3)
+        if ng[7]:
+            gW3 = _wgrad_raw(d3, h2, gy, W3, y, s3)
+        gh1 = _dgrad_raw(d2, gh2, nhwc(W2), h2, s2)
+        if ng[4]:
+            gW2 = _wgrad_raw(d2, h1, gh2, W2, h2, s2)
+        if ng[1]:
+            gW1 = _wgrad_raw(d1, x, gh1, W1, h1, s1)
+        if W4 is not None and ng[10]:
+            gW4 = _wgrad_raw(d4, x, gy, W4, y, s4)
+        if ng[0]:
+            if W4 is None:
+                # identity shortcut: gx = dgrad(conv1) + gy * (y > 0), added in the epilogue
+                gx = _dgrad_raw(d1, gh1, nhwc(W1), h1, s1, res_g=gy, res_y=y)
+            else:
+                gx = _dgrad_raw(d1, gh1, nhwc(W1), h1, s1)
+                _dgrad_raw(d4, gy, nhwc(W4), y, s4, out=gx, accum=True)
+        return (gx, gW1, None, None, gW2, None, None, gW3, None, None, gW4, None, None, None)
+
+
+def bottleneck(x, conv1, bn1, conv2, bn2, conv3, bn3, conv4=None, bn4=None, stride=1):
+    """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + shortcut) with
+    shortcut = bn4(conv4 x) (BottleneckA) or x (BottleneckB); stride lives in conv1/conv4."""
+    return _BottleneckFn.apply(
+        x, conv1.W, bn1.W, bn1.b, conv2.W, bn2.W, bn2.b, conv3.W, bn3.W, bn3.b,
+        None if conv4 is None else conv4.W, None if bn4 is None else bn4.W,
+        None if bn4 is None else bn4.b, stride)

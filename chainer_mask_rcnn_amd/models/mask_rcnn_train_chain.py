@@ -13,6 +13,17 @@ from .utils import AnchorTargetCreator
 from .utils import ProposalTargetCreator
 
 
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix='mrcnn-targets')
+    return _POOL
+
+
 class MaskRCNNTrainChain(torch.nn.Module):
 
     def __init__(self, mask_rcnn, rpn_sigma=3., roi_sigma=1.,
@@ -40,6 +51,14 @@ class MaskRCNNTrainChain(torch.nn.Module):
         img_size = (H, W)
 
         features = self.mask_rcnn.extractor(imgs)
+        # The deterministic half of the RPN target assignment needs only the ground truth:
+        # start it on worker threads now (NumPy releases the GIL) so it overlaps with the
+        # GPU's extractor/RPN/head work; its np.random draws happen later, in order.
+        anchor_h = self.mask_rcnn.rpn.host_anchor(features.shape[2], features.shape[3], dev)
+        atc = self.anchor_target_creator
+        atc_jobs = None
+        if hasattr(atc, 'prepare') and hasattr(atc, 'finish'):
+            atc_jobs = [_pool().submit(atc.prepare, bbox, anchor_h, img_size) for bbox in bboxes]
         rpn_locs, rpn_scores, rois, roi_indices, anchor = self.mask_rcnn.rpn(
             features, img_size, scales)
 
@@ -69,10 +88,12 @@ class MaskRCNNTrainChain(torch.nn.Module):
 
         # RPN targets (host) — after all ProposalTargetCreator calls, as in the reference,
         # so the global np.random stream is consumed in the same order (:150-158).
-        anchor_h = self.mask_rcnn.rpn.host_anchor(features.shape[2], features.shape[3], dev)
         gt_rpn_locs, gt_rpn_labels = [], []
-        for bbox in bboxes:
-            gt_rpn_loc, gt_rpn_label = self.anchor_target_creator(bbox, anchor_h, img_size)
+        for i, bbox in enumerate(bboxes):
+            if atc_jobs is not None:
+                gt_rpn_loc, gt_rpn_label = atc.finish(atc_jobs[i].result())
+            else:
+                gt_rpn_loc, gt_rpn_label = atc(bbox, anchor_h, img_size)
             gt_rpn_locs.append(gt_rpn_loc)
             gt_rpn_labels.append(gt_rpn_label)
         gt_rpn_locs = up(gt_rpn_locs, torch.float32)

@@ -65,6 +65,13 @@ class Bottleneck(torch.nn.Module):
             self.bn4 = AffineChannel2D(out_ch)
 
     def forward(self, x):
+        if self.projection:
+            return F.bottleneck(x, self.conv1, self.bn1, self.conv2, self.bn2, self.conv3,
+                                self.bn3, self.conv4, self.bn4, stride=self.conv1.stride)
+        return F.bottleneck(x, self.conv1, self.bn1, self.conv2, self.bn2, self.conv3, self.bn3)
+
+    def forward_unfused(self, x):
+        """Same block as four separate fused-conv autograd nodes (kept for testing)."""
         h = self.conv1(x, self.bn1, relu=True)
         h = self.conv2(h, self.bn2, relu=True)
         shortcut = self.conv4(x, self.bn4) if self.projection else x

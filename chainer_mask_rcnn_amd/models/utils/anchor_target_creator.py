@@ -18,6 +18,13 @@ class AnchorTargetCreator(object):
     def __call__(self, bbox, anchor, img_size):
         """bbox (G,4), anchor (S,4) host arrays, img_size (H,W) ->
         loc (S,4) f32 (0 outside), label (S,) i32 in {1,0,-1}."""
+        return self.finish(self.prepare(bbox, anchor, img_size))
+
+    def prepare(self, bbox, anchor, img_size):
+        """The deterministic part (IoU matrix, label rules, regression targets).  It needs
+        only the ground truth, so the train chain runs it on a worker thread while the GPU
+        is busy with the extractor; ``finish`` then draws from ``np.random`` on the caller's
+        thread, keeping the reference's global RNG order."""
         bbox = np.asarray(bbox, np.float32)
         anchor = np.asarray(anchor, np.float32)
         H, W = img_size
@@ -35,7 +42,11 @@ class AnchorTargetCreator(object):
         label[max_iou < self.neg_iou_thresh] = 0
         label[gt_argmax] = 1
         label[max_iou >= self.pos_iou_thresh] = 1
+        loc = bbox2loc(a, bbox[argmax])
+        return n_anchor, inside, label, loc
 
+    def finish(self, state):
+        n_anchor, inside, label, loc = state
         n_pos = int(self.pos_ratio * self.n_sample)
         pos = np.where(label == 1)[0]
         if len(pos) > n_pos:
@@ -45,7 +56,6 @@ class AnchorTargetCreator(object):
         if len(neg) > n_neg:
             label[np.random.choice(neg, size=len(neg) - n_neg, replace=False)] = -1
 
-        loc = bbox2loc(a, bbox[argmax])
         full_label = np.full((n_anchor,), -1, dtype=np.int32)
         full_label[inside] = label
         full_loc = np.zeros((n_anchor, 4), dtype=np.float32)

@@ -69,12 +69,46 @@ class ProposalTargetCreator(object):
         # bilinear weights (which sum to 1) and takes the argmax, i.e. fg prob > 0.5.
         M = self.mask_size
         gt_roi_mask = -np.ones((len(sample_roi), M, M), dtype=np.int32)
-        for i, idx in enumerate(fg):
-            y0, x0, y1, x1 = np.round(sample_roi[i]).astype(np.int32)
-            crop = mask[assigned[idx]][y0:y1, x0:x1]
-            if crop.size == 0 or crop.max() <= 0:
-                gt_roi_mask[i] = 0
-                continue
-            prob = resize_bilinear((crop > 0).astype(np.float32), M, M)
-            gt_roi_mask[i] = (prob > 0.5).astype(np.int32)
+        if n_fg > 0:
+            gt_roi_mask[:n_fg] = _mask_targets(
+                np.round(sample_roi[:n_fg]).astype(np.int32), assigned[fg], mask, M)
         return sample_roi, gt_roi_loc, gt_roi_label, gt_roi_mask
+
+
+def _mask_targets(boxes, gt_index, mask, M):
+    """(F, M, M) int32 mask targets for F integer boxes (y0, x0, y1, x1): bilinear resize
+    (cv2 INTER_LINEAR rule, utils.bbox.resize_bilinear) of each crop ``mask[g][y0:y1, x0:x1]``
+    to M x M, thresholded at 0.5 — all F crops in one vectorised gather."""
+    H, W = mask.shape[1:]
+    y0 = np.clip(boxes[:, 0], 0, H); y1 = np.clip(boxes[:, 2], 0, H)
+    x0 = np.clip(boxes[:, 1], 0, W); x1 = np.clip(boxes[:, 3], 0, W)
+    # Python slicing semantics of mask[y0:y1, x0:x1] for in-image integer boxes
+    h = np.maximum(y1 - y0, 0)
+    w = np.maximum(x1 - x0, 0)
+    ok = (h > 0) & (w > 0)
+
+    def axis(n_in, start):
+        n = np.maximum(n_in, 1).astype(np.float64)[:, None]
+        pos = (np.arange(M, dtype=np.float64)[None, :] + 0.5) * (n / float(M)) - 0.5
+        i0 = np.floor(pos).astype(np.int64)
+        t = (pos - i0).astype(np.float32)
+        edge = (i0 < 0) | (i0 >= n.astype(np.int64) - 1)
+        i0 = np.clip(i0, 0, n.astype(np.int64) - 1)
+        t[edge] = 0.
+        i1 = np.minimum(i0 + 1, n.astype(np.int64) - 1)
+        return i0 + start[:, None], i1 + start[:, None], t
+
+    ya, yb, ty = axis(h, y0)
+    xa, xb, tx = axis(w, x0)
+    ya, yb = np.clip(ya, 0, H - 1), np.clip(yb, 0, H - 1)
+    xa, xb = np.clip(xa, 0, W - 1), np.clip(xb, 0, W - 1)
+    g = np.asarray(gt_index)[:, None, None]
+    fgm = lambda yy, xx: (mask[g, yy[:, :, None], xx[:, None, :]] > 0).astype(np.float32)
+    tx_ = tx[:, None, :]
+    ty_ = ty[:, :, None]
+    top = fgm(ya, xa) * (1 - tx_) + fgm(ya, xb) * tx_
+    bot = fgm(yb, xa) * (1 - tx_) + fgm(yb, xb) * tx_
+    prob = top * (1 - ty_) + bot * ty_
+    out = (prob > 0.5).astype(np.int32)
+    out[~ok] = 0
+    return out

@@ -31,14 +31,23 @@ def enumerate_shifted_anchor(anchor_base, feat_stride, height, width):
 
 
 def bbox_iou(bbox_a, bbox_b):
-    """(len(a), len(b)) IoU matrix, no +1 terms."""
+    """(len(a), len(b)) IoU matrix, no +1 terms.
+
+    Same fp32 operation sequence as chainercv's broadcasting form
+    (``prod(br - tl, axis=2) * (tl < br).all(axis=2) / (area_a + area_b - inter)``),
+    written per coordinate so that no (A, B, 2) temporaries are reduced."""
     if bbox_a.shape[1] != 4 or bbox_b.shape[1] != 4:
         raise IndexError
-    tl = np.maximum(bbox_a[:, None, :2], bbox_b[None, :, :2])
-    br = np.minimum(bbox_a[:, None, 2:], bbox_b[None, :, 2:])
-    inter = np.prod(br - tl, axis=2) * (tl < br).all(axis=2)
-    area_a = np.prod(bbox_a[:, 2:] - bbox_a[:, :2], axis=1)
-    area_b = np.prod(bbox_b[:, 2:] - bbox_b[:, :2], axis=1)
+    a = np.asarray(bbox_a, np.float32)
+    b = np.asarray(bbox_b, np.float32)
+    ay1, ax1, ay2, ax2 = (a[:, i, None] for i in range(4))
+    by1, bx1, by2, bx2 = (b[None, :, i] for i in range(4))
+    tl_y, tl_x = np.maximum(ay1, by1), np.maximum(ax1, bx1)
+    br_y, br_x = np.minimum(ay2, by2), np.minimum(ax2, bx2)
+    inter = (br_y - tl_y) * (br_x - tl_x)
+    inter *= ((tl_y < br_y) & (tl_x < br_x))
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
     return inter / (area_a[:, None] + area_b[None, :] - inter)
 
 

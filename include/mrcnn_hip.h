@@ -139,6 +139,19 @@ int mrcnn_conv2d_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w
 int64_t mrcnn_conv2d_wgrad_workspace_bytes(const mrcnn_conv_desc *d);
 int mrcnn_conv2d_wgrad(const mrcnn_conv_desc *d, const float *x, const float *gy,
                        float *gw, void *ws, void *stream);
+/* Extended backward entry points with the producing conv's epilogue backward fused into
+ * the operand staging — g = gy * (mask_y > 0) * in_scale[k] is formed in registers on the
+ * way to LDS, so no elementwise pass over gy is needed (mask_y: output of the ReLU that
+ * followed the conv, same shape as gy; in_scale: its AffineChannel2D scale (K); either may
+ * be NULL).  dgrad additionally adds the identity-shortcut gradient of a bottleneck in its
+ * epilogue: gx += res_g * (res_y > 0) (both (N,H,W,C) or NULL; stride 1 only). */
+int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, const float *w,
+                          float *gx, int epi_flags, const float *mask_y,
+                          const float *in_scale, const float *res_g, const float *res_y,
+                          void *stream);
+int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float *gy,
+                          float *gw, void *ws, const float *mask_y, const float *in_scale,
+                          void *stream);
 /* Stem: conv1 7x7/2 pad 3 with bias of chainer ResNet50Layers (SURVEY.md A.1;
  * models/resnet_extractor.py:65-67) fused with bn1-as-affine and ReLU.  x4 is
  * the image padded to 4 channels (N,H,W,4); w784 is the filter laid out

@@ -178,3 +178,48 @@ def test_conv_linearity_at_full_size(dev):
     ws = Wt.double().cpu()
     ref = torch.nn.functional.conv2d(xs, ws, padding=1)
     assert (y1[1000:1001].double().cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('proj,stride', [(True, 2), (True, 1), (False, 1)])
+def test_fused_bottleneck_matches_oracle(dev, proj, stride):
+    """Whole-bottleneck node (mask/scale fused into dgrad/wgrad staging, shortcut gradient in
+    the dgrad epilogue) vs the NumPy oracle composed layer by layer."""
+    from chainer_mask_rcnn_amd.models.resnet_extractor import Bottleneck
+    torch.manual_seed(1)
+    rng = np.random.RandomState(17)
+    cin, mid, cout = (64, 32, 128) if proj else (128, 32, 128)
+    blk = Bottleneck(cin, mid, cout, stride, projection=proj).to(dev)
+    with torch.no_grad():
+        for m in [blk.bn1, blk.bn2, blk.bn3] + ([blk.bn4] if proj else []):
+            m.W.uniform_(0.5, 1.5)
+            m.b.normal_(0, 0.3)
+    x = rng.standard_normal((3, cin, 13, 10)).astype(np.float32)
+    xt = _t(x, dev, True)
+    y = blk(xt)
+    P = {n: p.detach().cpu().numpy() for n, p in blk.named_parameters()}
+    aff = np_ref.affine_channel_2d_fwd
+    p1 = aff(np_ref.conv2d_fwd(x, P['conv1.W'], None, stride, 0), P['bn1.W'], P['bn1.b'])
+    h1 = np.maximum(p1, 0)
+    p2 = aff(np_ref.conv2d_fwd(h1, P['conv2.W'], None, 1, 1), P['bn2.W'], P['bn2.b'])
+    h2 = np.maximum(p2, 0)
+    sc = aff(np_ref.conv2d_fwd(x, P['conv4.W'], None, stride, 0), P['bn4.W'], P['bn4.b']) if proj else x
+    p3 = aff(np_ref.conv2d_fwd(h2, P['conv3.W']), P['bn3.W'], P['bn3.b']) + sc
+    _close(y.detach().cpu().numpy(), np.maximum(p3, 0))
+    gy = rng.standard_normal(p3.shape).astype(np.float32)
+    y.backward(_t(gy, dev))
+    gr = gy * (p3 > 0)
+    gh2, gW3, _ = np_ref.conv2d_bwd(h2, P['conv3.W'], gr * P['bn3.W'][None, :, None, None])
+    g2 = gh2 * (p2 > 0) * P['bn2.W'][None, :, None, None]
+    gh1, gW2, _ = np_ref.conv2d_bwd(h1, P['conv2.W'], g2, 1, 1)
+    g1 = gh1 * (p1 > 0) * P['bn1.W'][None, :, None, None]
+    gx, gW1, _ = np_ref.conv2d_bwd(x, P['conv1.W'], g1, stride, 0)
+    if proj:
+        gx4, gW4, _ = np_ref.conv2d_bwd(x, P['conv4.W'], gr * P['bn4.W'][None, :, None, None], stride, 0)
+        gx = gx + gx4
+        _close(blk.conv4.W.grad.cpu().numpy(), gW4)
+    else:
+        gx = gx + gr
+    _close(xt.grad.cpu().numpy(), gx)
+    _close(blk.conv1.W.grad.cpu().numpy(), gW1)
+    _close(blk.conv2.W.grad.cpu().numpy(), gW2)
+    _close(blk.conv3.W.grad.cpu().numpy(), gW3)
