@@ -43,6 +43,7 @@ struct GemmParams {
     float *C;            // FWD: y      DGRAD: gx      WGRAD: gw / split slabs
     const float *bias, *scale, *shift, *residual;
     int M, N;            // output tile space (rows, cols)
+    int m_lo;            // first row handled by this launch (tail-split launches)
     int Kc;              // FWD: C_in   DGRAD: K_out   WGRAD: #pixels
     int gp, gq;          // pixel grid the rows (FWD/DGRAD) or K index (WGRAD) run over
     int sh, sw;          // spatial dims of the gathered tensor
@@ -143,7 +144,7 @@ conv_gemm_kernel(const GemmParams p)
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (tile / ntn) * BM;
+    const int m0 = p.m_lo + (tile / ntn) * BM;
     const int n0 = (tile % ntn) * BN;
 
     // ---------------- per-thread gather state -----------------------------------
@@ -465,25 +466,47 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, i
     }
 }
 
+// Workgroups resident at once: 128x128 tiles run 2 per CU (73 KB LDS), 64x64 tiles 4 per CU.
+constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
+
+template <int TM, int TN, int MODE>
+void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    p.m_lo = m_lo;
+    p.M = m_hi;
+    const int64_t blocks = mrcnn::ceil_div(m_hi - m_lo, BM) * mrcnn::ceil_div(p.N, BN);
+    if (blocks <= 0) return;
+    const int64_t rows = m_hi - m_lo;
+    const double kdepth = (double)p.R * p.S * (p.stem ? 21.0 : (double)p.Kc);
+    const double flops = 2.0 * rows * p.N * kdepth;
+    const double bytes = 4.0 * ((double)rows * p.N + (double)rows * p.Kc + (double)p.N * kdepth);
+    mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
+                              (TM == 2 ? 0 : 1),
+                          flops, bytes, s);
+    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE>), dim3((unsigned)blocks, splits), dim3(256), 0,
+                       s, p);
+}
+
+// FWD / DGRAD launch policy.  With T 128x128 tiles and 512 resident workgroups a launch
+// takes ceil(T/512) "rounds"; when the last round would be mostly empty (e.g. T = 536 or
+// 1568) the rows of the full rounds run as 128x128 tiles and the leftover rows as a second,
+// short launch of 64x64 tiles, instead of one nearly idle round of big tiles.
 template <int MODE>
 int launch(const GemmParams &p, int splits, hipStream_t s)
 {
-    // 128x128 tiles when they fill the chip at least ~1.5x, else 64x64.
-    const int64_t big = mrcnn::ceil_div(p.M, 128) * mrcnn::ceil_div(p.N, 128) * splits;
-    const bool use_big = big >= 384 && p.N > 64 && p.M > 64;
-    const double flops = 2.0 * p.M * p.N * (double)p.R * p.S * (p.stem ? 21.0 : (double)p.Kc);
-    const double bytes = 4.0 * ((double)p.M * p.N + (double)p.M * p.Kc + (double)p.N * p.R * p.S * p.Kc);
-    mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
-                              (use_big ? 0 : 1),
-                          flops, bytes, s);
-    if (use_big) {
-        const int64_t blocks = mrcnn::ceil_div(p.M, 128) * mrcnn::ceil_div(p.N, 128);
-        hipLaunchKernelGGL((conv_gemm_kernel<2, 2, MODE>), dim3((unsigned)blocks, splits), dim3(256),
-                           0, s, p);
+    const int64_t tm = mrcnn::ceil_div(p.M, 128), tn = mrcnn::ceil_div(p.N, 128);
+    const int64_t T = tm * tn;
+    const bool big_ok = p.N > 64 && p.M > 64;
+    if (!big_ok || T < 384) {
+        launch_tiles<1, 1, MODE>(p, 0, p.M, splits, s);
     } else {
-        const int64_t blocks = mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
-        hipLaunchKernelGGL((conv_gemm_kernel<1, 1, MODE>), dim3((unsigned)blocks, splits), dim3(256),
-                           0, s, p);
+        const int64_t full = T / kSlotsBig, rem = T - full * kSlotsBig;
+        int64_t main_tiles_m = tm;
+        if (full >= 1 && rem > 0 && rem * 10 < kSlotsBig * 6) main_tiles_m = (full * kSlotsBig) / tn;
+        const int rows_main = (int)std::min<int64_t>(p.M, main_tiles_m * 128);
+        launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
+        if (rows_main < p.M) launch_tiles<1, 1, MODE>(p, rows_main, p.M, splits, s);
     }
     return mrcnn::check_launch("conv_gemm");
 }
@@ -521,13 +544,20 @@ int set_extents(GemmParams &p, int64_t a_floats, int64_t b_floats, int64_t c_flo
     return 0;
 }
 
-int wgrad_splits(int64_t tiles, int64_t pixels)
+int wgrad_splits(int64_t tiles, int64_t pixels, int64_t slots)
 {
-    // enough workgroups to fill 256 CUs ~3x, each split at least 8 K slices deep
-    int64_t want = mrcnn::ceil_div(768, tiles);
-    int64_t maxs = std::max<int64_t>(1, pixels / (8 * BK));
-    int64_t s = std::max<int64_t>(1, std::min(want, maxs));
-    return (int)std::min<int64_t>(s, 64);
+    // Pick the split count whose tiles*splits workgroups fill whole rounds of `slots`
+    // resident workgroups best, each split at least 8 K slices deep, at most ~3 rounds.
+    const int64_t maxs = std::min<int64_t>(64, std::max<int64_t>(1, pixels / (8 * BK)));
+    int best = 1;
+    double best_u = -1.;
+    for (int64_t sp = 1; sp <= maxs; ++sp) {
+        const int64_t blocks = tiles * sp;
+        if (blocks > 3 * slots && sp > 1) break;
+        const double u = (double)blocks / (double)(mrcnn::ceil_div(blocks, slots) * slots);
+        if (u > best_u + 1e-9) { best_u = u; best = (int)sp; }
+    }
+    return best;
 }
 
 }  // namespace
@@ -653,7 +683,7 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     const int64_t tiles = (big >= 96 && p.N > 64 && p.M > 64)
                               ? big
                               : mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
-    int splits = wgrad_splits(tiles, pixels);
+    int splits = wgrad_splits(tiles, pixels, (big >= 96 && p.N > 64 && p.M > 64) ? kSlotsBig : kSlotsSmall);
     if (!ws) splits = 1;
     p.split_len = (int)(mrcnn::ceil_div(mrcnn::ceil_div(pixels, splits), BK) * BK);
     splits = (int)mrcnn::ceil_div(pixels, p.split_len);

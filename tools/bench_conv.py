@@ -1,0 +1,78 @@
+"""Developer tool: per-shape TFLOP/s of the implicit-GEMM conv family on the C2 shapes."""
+import sys, os, ctypes
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chainer_mask_rcnn_amd import _lib
+from chainer_mask_rcnn_amd.functions.conv import make_desc, ctx_desc
+from chainer_mask_rcnn_amd.functions._layout import empty_nhwc
+
+dev = torch.device('cuda:0')
+SHAPES = [
+    # name, N, C, H, W, K, k, stride, pad
+    ('stem-like res2 1x1 64->256', 2, 64, 201, 334, 256, 1, 1, 0),
+    ('res2 3x3 64', 2, 64, 201, 334, 64, 3, 1, 1),
+    ('res3a 1x1s2 256->128', 2, 256, 201, 334, 128, 1, 2, 0),
+    ('res3 3x3 128', 2, 128, 101, 167, 128, 3, 1, 1),
+    ('res3 1x1 128->512', 2, 128, 101, 167, 512, 1, 1, 0),
+    ('res3 1x1 512->128', 2, 512, 101, 167, 128, 1, 1, 0),
+    ('res4a 1x1s2 512->256', 2, 512, 101, 167, 256, 1, 2, 0),
+    ('res4 3x3 256', 2, 256, 51, 84, 256, 3, 1, 1),
+    ('res4 1x1 256->1024', 2, 256, 51, 84, 1024, 1, 1, 0),
+    ('res4 1x1 1024->256', 2, 1024, 51, 84, 256, 1, 1, 0),
+    ('rpn 3x3 1024', 2, 1024, 51, 84, 1024, 3, 1, 1),
+    ('res5a 1x1s2 1024->512', 1024, 1024, 14, 14, 512, 1, 2, 0),
+    ('res5a 1x1s2 1024->2048', 1024, 1024, 14, 14, 2048, 1, 2, 0),
+    ('res5 3x3 512', 1024, 512, 7, 7, 512, 3, 1, 1),
+    ('res5 1x1 512->2048', 1024, 512, 7, 7, 2048, 1, 1, 0),
+    ('res5 1x1 2048->512', 1024, 2048, 7, 7, 512, 1, 1, 0),
+    ('mask 1x1 256->80', 1024, 256, 14, 14, 80, 1, 1, 0),
+    ('fc 2048->408', 1024, 2048, 1, 1, 408, 1, 1, 0),
+]
+
+
+def timeit(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    lib = _lib.load()
+    tot = {'fwd': 0., 'dgrad': 0., 'wgrad': 0.}
+    print('%-28s %9s %9s %9s   (TFLOP/s | ms)' % ('shape', 'fwd', 'dgrad', 'wgrad'))
+    for name, N, C, H, W, K, k, s, p in SHAPES:
+        if only and only not in name:
+            continue
+        x = torch.randn((N, H, W, C), device=dev).permute(0, 3, 1, 2)
+        w = (torch.randn((K, k, k, C), device=dev) * 0.05).permute(0, 3, 1, 2)
+        d = make_desc(x.shape, w.shape, s, p)
+        y = empty_nhwc((d.N, d.K, d.P, d.Q), dev)
+        gy = torch.randn((d.N, d.P, d.Q, d.K), device=dev).permute(0, 3, 1, 2)
+        gx = empty_nhwc((N, C, H, W), dev)
+        gw = torch.empty_like(w)
+        ws = _lib.workspace(lib.mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)), dev, 'wgrad')
+        sp = _lib.stream_ptr()
+        flop = 2.0 * d.N * d.P * d.Q * K * C * k * k
+        f = lambda: _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(w), None, None,
+                              None, None, _lib.ptr(y), 0, sp)
+        g = lambda: _lib.call('mrcnn_conv2d_dgrad', ctx_desc(d), _lib.ptr(gy), _lib.ptr(w),
+                              _lib.ptr(gx), 0, sp)
+        h = lambda: _lib.call('mrcnn_conv2d_wgrad', ctx_desc(d), _lib.ptr(x), _lib.ptr(gy),
+                              _lib.ptr(gw), _lib.ptr(ws), sp)
+        tf, tg, th = timeit(f), timeit(g), timeit(h)
+        tot['fwd'] += tf; tot['dgrad'] += tg; tot['wgrad'] += th
+        print('%-28s %5.1f|%5.2f %5.1f|%5.2f %5.1f|%5.2f' % (
+            name, flop / tf / 1e9, tf, flop / tg / 1e9, tg, flop / th / 1e9, th))
+    print('sum ms', tot)
+
+
+if __name__ == '__main__':
+    main()
