@@ -61,7 +61,7 @@ def synthetic_batch(rng, batch, H, W, n_gt=8, n_fg_class=80):
     return imgs, bboxes, labels, masks, scales
 
 
-def build_trainer(n_layers, device, world, lr_batch):
+def build_trainer(n_layers, device, world, lr_batch, force_dp=False):
     import chainer_mask_rcnn_amd as cmr
     from chainer_mask_rcnn_amd import optimizers, parallel
     # examples/coco/train.py:36-38 + examples/train_common.py:160-169
@@ -84,7 +84,7 @@ def build_trainer(n_layers, device, world, lr_batch):
             optimizers.disable_update(m)
     stabilise_synthetic_weights(model)
     sync = None
-    if world > 1:
+    if world > 1 or force_dp:
         sync = parallel.DataParallelGradSync(opt)
     return model, chain, opt, sync
 
@@ -171,10 +171,17 @@ def main():
     ap.add_argument('--width', type=int, default=1333)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--force-dp', action='store_true',
+                    help='create a 1-rank RCCL group and run the data-parallel gradient path')
     args = ap.parse_args()
 
     from chainer_mask_rcnn_amd import parallel, _lib
     rank, world, local = parallel.init_from_env()
+    if args.force_dp and world == 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=0, world_size=1)
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     _lib.load()                                   # fail loudly without the HIP library
@@ -191,7 +198,8 @@ def main():
 
     rng = np.random.RandomState(rank)
     imgs, bboxes, labels, masks, scales = synthetic_batch(rng, args.batch, args.height, args.width)
-    model, chain, opt, sync = build_trainer(args.layers, device, world, args.batch * world)
+    model, chain, opt, sync = build_trainer(args.layers, device, world, args.batch * world,
+                                            force_dp=args.force_dp)
     imgs_d = torch.tensor(imgs, device=device).contiguous(memory_format=torch.channels_last)
 
     def step():
@@ -261,7 +269,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

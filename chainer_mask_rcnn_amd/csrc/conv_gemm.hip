@@ -312,44 +312,69 @@ conv_gemm_kernel(const GemmParams p)
 
     const int li = lane & 31, lk = lane >> 5;
 
+    // LDS -> MFMA fragments for the 8-deep K block kb of buffer `buf`
+    auto load_frag = [&](const float *sa, const float *sb, int kb, float (&af)[TM][4],
+                         float (&bf)[TN][4]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * (32 * TM) + i * 32 + li;
+            if (C_::A_KC) {
+                const float4 v = *reinterpret_cast<const float4 *>(
+                    sa + row * (BK + KPAD) + kb * 8 + lk * 4);
+                af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) af[i][t] = sa[(kb * 8 + lk * 4 + t) * BM + row];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * (32 * TN) + j * 32 + li;
+            if (C_::B_KC) {
+                const float4 v = *reinterpret_cast<const float4 *>(
+                    sb + col * (BK + KPAD) + kb * 8 + lk * 4);
+                bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bf[j][t] = sb[(kb * 8 + lk * 4 + t) * BN + col];
+            }
+        }
+    };
+
+    // one K slice: fragments of block kb+1 are fetched while block kb's MFMAs issue
     auto compute = [&](int buf) {
         const float *sa = smem[buf];
         const float *sb = smem[buf] + C_::A_FLOATS;
+        float af[2][TM][4], bf[2][TN][4];
+        load_frag(sa, sb, 0, af[0], bf[0]);
+        // DS read instructions per K block (b32 pairs are merged into ds_read2_b32)
+        constexpr int NR = (C_::A_KC ? TM : 2 * TM) + (C_::B_KC ? TN : 2 * TN);
+        constexpr int NMFMA = 4 * TM * TN;
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
-            float af[TM][4], bf[TN][4];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * (32 * TM) + i * 32 + li;
-                if (C_::A_KC) {
-                    const float4 v = *reinterpret_cast<const float4 *>(
-                        sa + row * (BK + KPAD) + kb * 8 + lk * 4);
-                    af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) af[i][t] = sa[(kb * 8 + lk * 4 + t) * BM + row];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = wn * (32 * TN) + j * 32 + li;
-                if (C_::B_KC) {
-                    const float4 v = *reinterpret_cast<const float4 *>(
-                        sb + col * (BK + KPAD) + kb * 8 + lk * 4);
-                    bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) bf[j][t] = sb[(kb * 8 + lk * 4 + t) * BN + col];
-                }
-            }
+            if (kb + 1 < BK / 8) load_frag(sa, sb, kb + 1, af[(kb + 1) & 1], bf[(kb + 1) & 1]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t],
-                                                                         acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            af[kb & 1][i][t], bf[kb & 1][j][t], acc[i][j], 0, 0, 0);
+            // pin the issue order: the next block's LDS reads ride behind this block's first
+            // MFMAs instead of being sunk in front of their consumers (which exposes the
+            // LDS latency once per 4 MFMAs)
+            if (kb + 1 < BK / 8) {
+#define MRCNN_SGB_STEP(q)                                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
+    __builtin_amdgcn_sched_group_barrier(0x100, (NR + 3 - (q)) / 4, 0);
+                MRCNN_SGB_STEP(0) MRCNN_SGB_STEP(1) MRCNN_SGB_STEP(2) MRCNN_SGB_STEP(3)
+#undef MRCNN_SGB_STEP
+                __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - 4, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+            }
         }
     };
 

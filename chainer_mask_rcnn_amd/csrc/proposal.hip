@@ -191,6 +191,69 @@ extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, 
     return mrcnn::check_launch("topk_desc");
 }
 
+// ---- per-class score threshold + stable sort + gather for MaskRCNN._suppress ----------------
+// (models/mask_rcnn.py:178-202 does this per class in a Python loop on CPU copies.)
+namespace {
+__global__ void detect_keys_kernel(const float *__restrict__ prob, int R, int n_class, float thresh,
+                                   uint64_t *__restrict__ keys, int32_t *__restrict__ counts)
+{
+    const int g = blockIdx.y;                       // foreground class g -> column g + 1
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool v = false;
+    if (i < R) {
+        const float p = prob[(int64_t)i * n_class + g + 1];
+        v = p > thresh;
+        keys[(int64_t)g * R + i] = v ? make_key(p, i) : 0ull;
+    }
+    const unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counts[g], (int)__popcll(b));
+}
+
+__global__ void __launch_bounds__(256)
+detect_rank_gather_kernel(const uint64_t *__restrict__ keys, const float *__restrict__ prob,
+                          const float4 *__restrict__ cls_bbox, int R, int n_class,
+                          float4 *__restrict__ sorted_boxes, float *__restrict__ sorted_prob)
+{
+    const int g = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t *__restrict__ kg = keys + (int64_t)g * R;
+    const uint64_t ki = i < R ? kg[i] : 0ull;
+    int cnt = 0;
+    for (int j = 0; j < R; ++j) cnt += kg[j] > ki;
+    if (i < R && ki != 0ull) {
+        sorted_boxes[(int64_t)g * R + cnt] = cls_bbox[(int64_t)i * n_class + g + 1];
+        sorted_prob[(int64_t)g * R + cnt] = prob[(int64_t)i * n_class + g + 1];
+    }
+}
+}  // namespace
+
+extern "C" int64_t mrcnn_detect_sort_workspace_bytes(int R, int n_class)
+{
+    return (int64_t)R * (n_class - 1) * 8 + 64;
+}
+
+extern "C" int mrcnn_detect_sort(const float *prob, const float *cls_bbox, int R, int n_class,
+                                 float thresh, float *sorted_boxes, float *sorted_prob,
+                                 int32_t *counts, void *ws, void *stream)
+{
+    MRCNN_REQUIRE(R >= 0 && n_class >= 2, "detect_sort: bad shape");
+    MRCNN_REQUIRE(counts, "detect_sort: null counts");
+    hipStream_t s = mrcnn::as_stream(stream);
+    const int G = n_class - 1;
+    MRCNN_HIP_TRY(hipMemsetAsync(counts, 0, 4 * (size_t)G, s));
+    if (R == 0) return 0;
+    MRCNN_REQUIRE(prob && cls_bbox && sorted_boxes && sorted_prob && ws, "detect_sort: null pointer");
+    MRCNN_REQUIRE(((uintptr_t)cls_bbox | (uintptr_t)sorted_boxes) % 16 == 0,
+                  "detect_sort: boxes must be 16-byte aligned");
+    const int blocks = (int)mrcnn::ceil_div(R, 256);
+    hipLaunchKernelGGL(detect_keys_kernel, dim3(blocks, G), dim3(256), 0, s, prob, R, n_class, thresh,
+                       (uint64_t *)ws, counts);
+    hipLaunchKernelGGL(detect_rank_gather_kernel, dim3(blocks, G), dim3(256), 0, s,
+                       (const uint64_t *)ws, prob, (const float4 *)cls_bbox, R, n_class,
+                       (float4 *)sorted_boxes, sorted_prob);
+    return mrcnn::check_launch("detect_sort");
+}
+
 extern "C" int mrcnn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev,
                                  int n_max, int cols, float *dst, void *stream)
 {

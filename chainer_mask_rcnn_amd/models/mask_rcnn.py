@@ -59,17 +59,14 @@ class MaskRCNN(torch.nn.Module):
         R = cls_bbox.shape[0]
         n_fg = self.n_class - 1
         dev = cls_bbox.device
-        sorted_boxes = torch.zeros((n_fg, R, 4), dtype=torch.float32, device=dev)
-        sorted_prob = torch.zeros((n_fg, R), dtype=torch.float32, device=dev)
-        counts = torch.zeros((n_fg,), dtype=torch.int32, device=dev)
-        probT = prob.t().contiguous()                       # (n_class, R)
-        boxT = cls_bbox.permute(1, 0, 2).contiguous()       # (n_class, R, 4)
-        for l in range(1, self.n_class):
-            valid = (probT[l] > self.score_thresh).to(torch.uint8)
-            order, n_out = P.topk_desc(probT[l], R, valid)
-            sorted_boxes[l - 1] = P.gather_rows(boxT[l], order, n_out)
-            sorted_prob[l - 1] = P.gather_rows(probT[l][:, None].contiguous(), order, n_out)[:, 0]
-            counts[l - 1:l] = n_out
+        sorted_boxes = torch.empty((n_fg, max(R, 1), 4), dtype=torch.float32, device=dev)
+        sorted_prob = torch.empty((n_fg, max(R, 1)), dtype=torch.float32, device=dev)
+        counts = torch.empty((n_fg,), dtype=torch.int32, device=dev)
+        ws = _lib.workspace(_lib.load().mrcnn_detect_sort_workspace_bytes(R, self.n_class), dev,
+                            'detect')
+        _lib.call('mrcnn_detect_sort', _lib.ptr(prob.contiguous()), _lib.ptr(cls_bbox.contiguous()),
+                  R, self.n_class, float(self.score_thresh), _lib.ptr(sorted_boxes),
+                  _lib.ptr(sorted_prob), _lib.ptr(counts), _lib.ptr(ws), _lib.stream_ptr())
         keep, n_keep = P.nms_sorted_batched(sorted_boxes, counts, self.nms_thresh)
         keep, n_keep = keep.cpu().numpy(), n_keep.cpu().numpy()
         sorted_boxes, sorted_prob = sorted_boxes.cpu().numpy(), sorted_prob.cpu().numpy()

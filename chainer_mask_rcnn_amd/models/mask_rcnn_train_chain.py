@@ -37,6 +37,7 @@ class MaskRCNNTrainChain(torch.nn.Module):
         self.loc_normalize_mean = mask_rcnn.loc_normalize_mean
         self.loc_normalize_std = mask_rcnn.loc_normalize_std
         self.report = {}
+        self.features_grad_hook = None     # set by parallel.DataParallelGradSync
 
     def forward(self, imgs, bboxes, labels, masks, scales):
         """imgs (N,3,H,W) device tensor; bboxes / labels / masks: per-image sequences of
@@ -51,6 +52,9 @@ class MaskRCNNTrainChain(torch.nn.Module):
         img_size = (H, W)
 
         features = self.mask_rcnn.extractor(imgs)
+        if self.features_grad_hook is not None and features.requires_grad:
+            # fires once the head's and the RPN's backward are both done
+            features.register_hook(self.features_grad_hook)
         # The deterministic half of the RPN target assignment needs only the ground truth:
         # start it on worker threads now (NumPy releases the GIL) so it overlaps with the
         # GPU's extractor/RPN/head work; its np.random draws happen later, in order.

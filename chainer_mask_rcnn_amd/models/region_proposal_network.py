@@ -71,12 +71,13 @@ class RegionProposalNetwork(torch.nn.Module):
         rpn_scores = nhwc[..., 4 * A:5 * A].reshape(n, -1)
 
         self.proposal_layer.train = self.training
-        rois, roi_indices = [], []
-        for i in range(n):
-            roi = self.proposal_layer(rpn_locs[i], rpn_scores[i], anchor, img_size,
-                                      scale=float(scales[i]))
-            rois.append(roi)
-            roi_indices.append(torch.full((len(roi),), i, dtype=torch.int32, device=x.device))
+        if hasattr(self.proposal_layer, 'batch'):
+            rois = self.proposal_layer.batch(rpn_locs, rpn_scores, anchor, img_size, scales)
+        else:
+            rois = [self.proposal_layer(rpn_locs[i], rpn_scores[i], anchor, img_size,
+                                        scale=float(scales[i])) for i in range(n)]
+        roi_indices = [torch.full((len(roi),), i, dtype=torch.int32, device=x.device)
+                       for i, roi in enumerate(rois)]
         rois = torch.cat(rois, dim=0)
         roi_indices = torch.cat(roi_indices, dim=0)
         return rpn_locs, rpn_scores, rois, roi_indices, anchor

@@ -131,6 +131,9 @@ class ResNetExtractorBase(torch.nn.Module):
         if not remove_layers or 'res5' not in remove_layers:
             self.res5 = BuildingBlock(n[3], 1024, 512, 2048, 2)
         self._stem_cache = None
+        # optional {stage name: tensor hook}; parallel.DataParallelGradSync uses 'res3' to
+        # learn that res4's gradients are complete
+        self.stage_hooks = {}
 
     def _stem(self, x):
         # conv1 and bn1 are frozen (examples/train_common.py:185-187): pack once per weight version
@@ -167,6 +170,9 @@ class ResNetExtractorBase(torch.nn.Module):
             if key == self.freeze_at:
                 h = h.detach()          # Variable.unchain_backward()
                 frozen = False
+            hook = self.stage_hooks.get(key)
+            if hook is not None and h.requires_grad:
+                h.register_hook(hook)   # fires when backward has passed this stage
             if key == self.target_layer:
                 break
         return h

@@ -41,3 +41,30 @@ class ProposalCreator(object):
         if return_indices:
             return out, order[keep.long()]
         return out
+
+    def batch(self, locs, scores, anchor, img_size, scales):
+        """All images of a batch at once: per-image decode / top-k / gather are queued
+        without synchronising, the NMS of every image runs in ONE batched launch (one
+        workgroup scans each image's mask concurrently) and the kept counts come back in a
+        single host read.  Same results as calling the object once per image."""
+        if self.train:
+            n_pre, n_post = self.n_train_pre_nms, self.n_train_post_nms
+        else:
+            n_pre, n_post = self.n_test_pre_nms, self.n_test_post_nms
+        n = len(locs)
+        S = anchor.shape[0]
+        k = min(n_pre, S) if n_pre > 0 else S
+        dev = anchor.device
+        sorted_rois = torch.empty((n, k, 4), dtype=torch.float32, device=dev)
+        counts = torch.empty((n,), dtype=torch.int32, device=dev)
+        for i in range(n):
+            roi, valid = P.decode_clip(anchor, locs[i].detach(), img_size,
+                                       float(self.min_size) * float(scales[i]))
+            order, n_sorted = P.topk_desc(scores[i].detach().reshape(-1), k, valid)
+            sorted_rois[i] = P.gather_rows(roi, order, n_sorted)
+            counts[i:i + 1] = n_sorted
+        keep, n_keep = P.nms_sorted_batched(sorted_rois, counts, self.nms_thresh,
+                                            limit=n_post if n_post > 0 else 0)
+        n_keep = n_keep.cpu().tolist()           # the one host synchronisation
+        return [P.gather_rows(sorted_rois[i], keep[i, :n_keep[i]].contiguous())
+                for i in range(n)]

@@ -85,6 +85,13 @@ class DataParallelGradSync(object):
                 break
             bounds.append(arena.slice_bounds(idx[0], idx[-1]))
         self.buckets = GradBuckets(arena.grads, bounds, self.group)
+        # wire the bucket triggers into the model (duck-typed: a MaskRCNNTrainChain)
+        target = optimizer.target
+        if len(bounds) == 3 and hasattr(target, 'features_grad_hook'):
+            target.features_grad_hook = self.stage_hook(0)
+            extractor = getattr(getattr(target, 'mask_rcnn', None), 'extractor', None)
+            if extractor is not None and hasattr(extractor, 'stage_hooks'):
+                extractor.stage_hooks['res3'] = self.stage_hook(1)
 
     # -- per step ----------------------------------------------------------------
     def begin_backward(self):

@@ -229,6 +229,15 @@ int mrcnn_sgd_momentum_wd(float *p, const float *g, float *v, int64_t n, float l
                           float momentum, float wd, float grad_scale,
                           void *stream);
 
+/* Per-class `prob > thresh` filter + stable descending sort + gather, all foreground
+ * classes in one launch: the first half of MaskRCNN._suppress (models/mask_rcnn.py:178-202).
+ * prob (R, n_class), cls_bbox (R, n_class, 4) -> sorted_boxes (n_class-1, R, 4),
+ * sorted_prob (n_class-1, R), counts (n_class-1); feed to mrcnn_nms_sorted_batched. */
+int64_t mrcnn_detect_sort_workspace_bytes(int R, int n_class);
+int mrcnn_detect_sort(const float *prob, const float *cls_bbox, int R, int n_class,
+                      float thresh, float *sorted_boxes, float *sorted_prob,
+                      int32_t *counts, void *ws, void *stream);
+
 /* ---- Inference post-processing (models/mask_rcnn.py:204-265) ---------------- */
 /* Per-class decode: cls_bbox[r,l,:] = clip(loc2bbox(roi[r]/scale,
  * cls_loc[r,l,:]*std+mean), 0, size) for all classes (:225-240). */
