@@ -194,6 +194,7 @@ conv_gemm_kernel(const GemmParams p)
         }
     }
 
+    const int adv_x = BK % p.gq, adv_y = (BK / p.gq) % p.gp, adv_n = BK / (p.gp * p.gq);
     const int cprs = (MODE == WGRAD) ? 1 : (p.Kc + BK - 1) / BK;  // K slices per (r,s)
     const int nslices = (MODE == WGRAD) ? (k_end - k_begin + BK - 1) / BK : p.R * p.S * cprs;
 
@@ -263,16 +264,15 @@ conv_gemm_kernel(const GemmParams p)
                                 (unsigned)ix < (unsigned)p.sw;
                 rb[i] = bload4(rB, ok ? 4u * (unsigned)(((pn[i] * p.sh + iy) * p.sw + ix) * p.lda + wc)
                                       : kOOB);
-                // advance this row's pixel by BK for the next slice
-                if (p.gp * p.gq == 1) {
-                    pn[i] += BK;
-                } else {
-                    px[i] += BK;
-                    while (px[i] >= p.gq) {
-                        px[i] -= p.gq;
-                        if (++py[i] >= p.gp) { py[i] = 0; ++pn[i]; }
-                    }
-                }
+                // advance this row's pixel by BK for the next slice (two carries, no loops:
+                // adv_x = BK % gq, adv_y = (BK / gq) % gp, adv_n = BK / (gp*gq))
+                px[i] += adv_x;
+                const int cx = px[i] >= p.gq;
+                px[i] -= cx ? p.gq : 0;
+                py[i] += adv_y + cx;
+                const int cy = py[i] >= p.gp;
+                py[i] -= cy ? p.gp : 0;
+                pn[i] += adv_n + cy;
             }
         }
     };
@@ -705,18 +705,20 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     p.lda = C; p.ldg = ldg; p.cin = C; p.ldc = R * S * C;
     const int64_t gwsz = (int64_t)Kout * R * S * C;
     const int64_t big = mrcnn::ceil_div(p.M, 128) * mrcnn::ceil_div(p.N, 128);
-    const int64_t tiles = (big >= 96 && p.N > 64 && p.M > 64)
-                              ? big
-                              : mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
-    int splits = wgrad_splits(tiles, pixels, (big >= 96 && p.N > 64 && p.M > 64) ? kSlotsBig : kSlotsSmall);
+    // The pixel (K) dimension supplies the parallelism through split-K, so 128x128 tiles are
+    // used whenever tiles x achievable splits fills at least half of the resident slots and
+    // the problem is at least one tile wide; otherwise 64x64 tiles.
+    const int64_t small = mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
+    const int64_t max_splits = std::min<int64_t>(64, std::max<int64_t>(1, pixels / (8 * BK)));
+    const bool use_big = p.N > 64 && p.M > 64 && big * max_splits * 2 >= kSlotsBig;
+    const int64_t tiles = use_big ? big : small;
+    int splits = wgrad_splits(tiles, pixels, use_big ? kSlotsBig : kSlotsSmall);
     if (!ws) splits = 1;
     p.split_len = (int)(mrcnn::ceil_div(mrcnn::ceil_div(pixels, splits), BK) * BK);
     splits = (int)mrcnn::ceil_div(pixels, p.split_len);
     p.split_stride = gwsz;
     if (int rc = set_extents(p, pixels * ldg, (int64_t)N_ * H * W * C, gwsz)) return rc;
     p.C = splits > 1 ? (float *)ws : gw;
-    // tile-size choice must agree with `tiles` above
-    const bool use_big = big >= 96 && p.N > 64 && p.M > 64;
     mrcnn::ProfScope prof(use_big ? mrcnn::PROF_CONV_WGRAD_128 : mrcnn::PROF_CONV_WGRAD_64,
                           2.0 * p.M * p.N * (double)pixels,
                           4.0 * ((double)p.M * p.N + (double)pixels * (p.M + (double)C)), s);
