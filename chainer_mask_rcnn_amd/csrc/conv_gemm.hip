@@ -32,6 +32,10 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
+#ifndef MRCNN_GEMM_SETPRIO
+#define MRCNN_GEMM_SETPRIO 0
+#endif
+constexpr bool SETPRIO = MRCNN_GEMM_SETPRIO != 0;
 constexpr int KPAD = 4;  // K-contiguous LDS rows are 36 floats (conflict-free b128)
 
 enum Mode { FWD = 0, DGRAD = 1, WGRAD = 2 };
@@ -347,6 +351,7 @@ conv_gemm_kernel(const GemmParams p)
         const float *sb = smem[buf] + C_::A_FLOATS;
         float af[2][TM][4], bf[2][TN][4];
         load_frag(sa, sb, 0, af[0], bf[0]);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
         // DS read instructions per K block (b32 pairs are merged into ds_read2_b32)
         constexpr int NR = (C_::A_KC ? TM : 2 * TM) + (C_::B_KC ? TN : 2 * TN);
         constexpr int NMFMA = 4 * TM * TN;
@@ -376,6 +381,7 @@ conv_gemm_kernel(const GemmParams p)
                 __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
             }
         }
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     if (nslices > 0) {

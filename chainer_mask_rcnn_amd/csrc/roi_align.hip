@@ -102,12 +102,14 @@ template <> struct VecOps<float4> {
 template <typename V>
 __global__ void roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois,
                                      V *__restrict__ y, int H, int W, int CV, int PH, int PW,
-                                     float spatial_scale, int sampling_ratio)
+                                     float spatial_scale, int sampling_ratio, int OH, int OW,
+                                     int BS)
 {
-    const int bin = blockIdx.x;  // ((n*PH)+ph)*PW+pw
-    const int pw = bin % PW;
-    const int ph = (bin / PW) % PH;
-    const int n = bin / (PW * PH);
+    // output bin (oh, ow) is bin (oh*BS, ow*BS) of the PH x PW grid (BS = 1: every bin)
+    const int bin = blockIdx.x;  // ((n*OH)+oh)*OW+ow
+    const int pw = (bin % OW) * BS;
+    const int ph = ((bin / OW) % OH) * BS;
+    const int n = bin / (OW * OH);
     const RoiGeom g = roi_geom(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio);
     const V *__restrict__ img = x + (int64_t)g.batch * H * W * CV;
     V *__restrict__ out = y + (int64_t)bin * CV;
@@ -160,12 +162,13 @@ __device__ __forceinline__ float4 scale_div(float4 d, float w, float c)
 template <typename V>
 __global__ void roi_align_bwd_kernel(const V *__restrict__ gy, const float *__restrict__ rois,
                                      V *__restrict__ gx, int H, int W, int CV, int PH, int PW,
-                                     float spatial_scale, int sampling_ratio)
+                                     float spatial_scale, int sampling_ratio, int OH, int OW,
+                                     int BS)
 {
     const int bin = blockIdx.x;
-    const int pw = bin % PW;
-    const int ph = (bin / PW) % PH;
-    const int n = bin / (PW * PH);
+    const int pw = (bin % OW) * BS;
+    const int ph = ((bin / OW) % OH) * BS;
+    const int n = bin / (OW * OH);
     const RoiGeom g = roi_geom(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio);
     V *__restrict__ img = gx + (int64_t)g.batch * H * W * CV;
     const V *__restrict__ top = gy + (int64_t)bin * CV;
@@ -207,7 +210,7 @@ template <typename V>
 __global__ void __launch_bounds__(256)
 roi_align_bwd_gather_kernel(const V *__restrict__ gy, const float *__restrict__ rois,
                             V *__restrict__ gx, int H, int W, int CV, int PH, int PW,
-                            float spatial_scale, int sampling_ratio)
+                            float spatial_scale, int sampling_ratio, int OH, int OW, int BS)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = blockIdx.y;
@@ -230,7 +233,8 @@ roi_align_bwd_gather_kernel(const V *__restrict__ gy, const float *__restrict__ 
     float *Bx = lds + PH;                  // [PX][PW]
     int *pwlo = reinterpret_cast<int *>(Bx + (W + 4) * PW);  // [PX]
     int *pwhi = pwlo + (W + 4);
-    for (int ph = threadIdx.x; ph < PH; ph += blockDim.x) {
+    for (int oh = threadIdx.x; oh < OH; oh += blockDim.x) {
+        const int ph = oh * BS;
         float a = 0.f;
         for (int iy = 0; iy < g.grid_h; ++iy) {
             const float yy = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
@@ -239,10 +243,11 @@ roi_align_bwd_gather_kernel(const V *__restrict__ gy, const float *__restrict__ 
             if (t.lo == y) a += t.h;
             if (t.hi == y) a += t.l;
         }
-        Ay[ph] = a;
+        Ay[oh] = a;
     }
-    for (int e = threadIdx.x; e < PX * PW; e += blockDim.x) {
-        const int xi = e / PW, pw = e - xi * PW;
+    for (int e = threadIdx.x; e < PX * OW; e += blockDim.x) {
+        const int xi = e / OW, ow_ = e - xi * OW;
+        const int pw = ow_ * BS;
         const int x = xlo + xi;
         float b = 0.f;
         for (int ix = 0; ix < g.grid_w; ++ix) {
@@ -256,20 +261,20 @@ roi_align_bwd_gather_kernel(const V *__restrict__ gy, const float *__restrict__ 
     }
     __syncthreads();
     for (int xi = threadIdx.x; xi < PX; xi += blockDim.x) {
-        int lo = PW, hi = -1;
-        for (int pw = 0; pw < PW; ++pw)
-            if (Bx[xi * PW + pw] != 0.f) { lo = min(lo, pw); hi = pw; }
+        int lo = OW, hi = -1;
+        for (int pw = 0; pw < OW; ++pw)
+            if (Bx[xi * OW + pw] != 0.f) { lo = min(lo, pw); hi = pw; }
         pwlo[xi] = lo;
         pwhi[xi] = hi;
     }
     __syncthreads();
-    int phlo = PH, phhi = -1;
-    for (int ph = 0; ph < PH; ++ph)
+    int phlo = OH, phhi = -1;
+    for (int ph = 0; ph < OH; ++ph)
         if (Ay[ph] != 0.f) { phlo = min(phlo, ph); phhi = ph; }
     if (phhi < 0) return;
 
     const float inv_count = 1.f / g.count;
-    const V *__restrict__ top = gy + (int64_t)n * PH * PW * CV;
+    const V *__restrict__ top = gy + (int64_t)n * OH * OW * CV;
     V *__restrict__ row = gx + (((int64_t)g.batch * H + y) * W + xlo) * CV;
     for (int c = threadIdx.x; c < CV; c += blockDim.x) {
         for (int xi = 0; xi < PX; ++xi) {
@@ -280,7 +285,7 @@ roi_align_bwd_gather_kernel(const V *__restrict__ gy, const float *__restrict__ 
                 const float ay = Ay[ph] * inv_count;
                 if (ay == 0.f) continue;
                 for (int pw = l; pw <= h; ++pw)
-                    acc = vfma(acc, ay * Bx[xi * PW + pw], top[((int64_t)ph * PW + pw) * CV + c]);
+                    acc = vfma(acc, ay * Bx[xi * OW + pw], top[((int64_t)ph * OW + pw) * CV + c]);
             }
             atomic_add_vec(&row[(int64_t)xi * CV + c], acc);
         }
@@ -307,40 +312,53 @@ int check_args(const void *a, const void *b, const void *c, int N, int H, int W,
 
 }  // namespace
 
-extern "C" int mrcnn_roi_align_fwd(const float *x, const float *rois, float *y, int N, int H,
-                                   int W, int C, int R, int PH, int PW, float spatial_scale,
-                                   int sampling_ratio, void *stream)
+extern "C" int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *y, int N, int H,
+                                      int W, int C, int R, int PH, int PW, int bin_stride,
+                                      float spatial_scale, int sampling_ratio, void *stream)
 {
     if (int rc = check_args(x, rois, y, N, H, W, C, R, PH, PW, sampling_ratio)) return rc;
+    MRCNN_REQUIRE(bin_stride >= 1, "roi_align: bin_stride must be >= 1");
     if (R == 0) return 0;
-    const int bins = R * PH * PW;
+    const int OH = (PH + bin_stride - 1) / bin_stride, OW = (PW + bin_stride - 1) / bin_stride;
+    const int bins = R * OH * OW;
     hipStream_t s = mrcnn::as_stream(stream);
-    // algorithmic bytes: write R*PH*PW*C, read the feature maps once
+    // algorithmic bytes: write R*OH*OW*C, read the feature maps once
     mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_FWD, 0.,
                           4.0 * ((double)bins * C + (double)N * H * W * C), s);
     if (C % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0)) {
         const int cv = C / 4;
         hipLaunchKernelGGL(roi_align_fwd_kernel<float4>, dim3(bins), dim3(pick_threads(cv)), 0, s,
                            (const float4 *)x, rois, (float4 *)y, H, W, cv, PH, PW, spatial_scale,
-                           sampling_ratio);
+                           sampling_ratio, OH, OW, bin_stride);
     } else {
         hipLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3(bins), dim3(pick_threads(C)), 0, s, x,
-                           rois, y, H, W, C, PH, PW, spatial_scale, sampling_ratio);
+                           rois, y, H, W, C, PH, PW, spatial_scale, sampling_ratio, OH, OW,
+                           bin_stride);
     }
     return mrcnn::check_launch("roi_align_fwd");
 }
 
-extern "C" int mrcnn_roi_align_bwd(const float *gy, const float *rois, float *gx, int N, int H,
+extern "C" int mrcnn_roi_align_fwd(const float *x, const float *rois, float *y, int N, int H,
                                    int W, int C, int R, int PH, int PW, float spatial_scale,
                                    int sampling_ratio, void *stream)
 {
+    return mrcnn_roi_align_fwd_ex(x, rois, y, N, H, W, C, R, PH, PW, 1, spatial_scale,
+                                  sampling_ratio, stream);
+}
+
+extern "C" int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float *gx, int N, int H,
+                                      int W, int C, int R, int PH, int PW, int bin_stride,
+                                      float spatial_scale, int sampling_ratio, void *stream)
+{
     if (int rc = check_args(gy, rois, gx, N, H, W, C, R, PH, PW, sampling_ratio)) return rc;
+    MRCNN_REQUIRE(bin_stride >= 1, "roi_align: bin_stride must be >= 1");
     hipStream_t s = mrcnn::as_stream(stream);
     MRCNN_REQUIRE(gx != nullptr, "roi_align_bwd: null gx");
     MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * H * W * C, s));
     if (R == 0) return 0;
-    const int bins = R * PH * PW;
-    // algorithmic bytes: read R*PH*PW*C, read-modify-write the feature-map gradient
+    const int OH = (PH + bin_stride - 1) / bin_stride, OW = (PW + bin_stride - 1) / bin_stride;
+    const int bins = R * OH * OW;
+    // algorithmic bytes: read R*OH*OW*C, read-modify-write the feature-map gradient
     mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_BWD, 0.,
                           4.0 * ((double)bins * C + 2.0 * (double)N * H * W * C), s);
     const bool vec = C % 4 == 0 && ((uintptr_t)gx % 16 == 0) && ((uintptr_t)gy % 16 == 0);
@@ -350,17 +368,28 @@ extern "C" int mrcnn_roi_align_bwd(const float *gy, const float *rois, float *gx
         if (vec)
             hipLaunchKernelGGL(roi_align_bwd_gather_kernel<float4>, dim3(H, R),
                                dim3(pick_threads(C / 4)), lds, s, (const float4 *)gy, rois,
-                               (float4 *)gx, H, W, C / 4, PH, PW, spatial_scale, sampling_ratio);
+                               (float4 *)gx, H, W, C / 4, PH, PW, spatial_scale, sampling_ratio,
+                               OH, OW, bin_stride);
         else
             hipLaunchKernelGGL(roi_align_bwd_gather_kernel<float>, dim3(H, R), dim3(pick_threads(C)),
-                               lds, s, gy, rois, gx, H, W, C, PH, PW, spatial_scale, sampling_ratio);
+                               lds, s, gy, rois, gx, H, W, C, PH, PW, spatial_scale, sampling_ratio,
+                               OH, OW, bin_stride);
     } else if (vec) {
         hipLaunchKernelGGL(roi_align_bwd_kernel<float4>, dim3(bins), dim3(pick_threads(C / 4)), 0, s,
                            (const float4 *)gy, rois, (float4 *)gx, H, W, C / 4, PH, PW,
-                           spatial_scale, sampling_ratio);
+                           spatial_scale, sampling_ratio, OH, OW, bin_stride);
     } else {
         hipLaunchKernelGGL(roi_align_bwd_kernel<float>, dim3(bins), dim3(pick_threads(C)), 0, s, gy,
-                           rois, gx, H, W, C, PH, PW, spatial_scale, sampling_ratio);
+                           rois, gx, H, W, C, PH, PW, spatial_scale, sampling_ratio, OH, OW,
+                           bin_stride);
     }
     return mrcnn::check_launch("roi_align_bwd");
+}
+
+extern "C" int mrcnn_roi_align_bwd(const float *gy, const float *rois, float *gx, int N, int H,
+                                   int W, int C, int R, int PH, int PW, float spatial_scale,
+                                   int sampling_ratio, void *stream)
+{
+    return mrcnn_roi_align_bwd_ex(gy, rois, gx, N, H, W, C, R, PH, PW, 1, spatial_scale,
+                                  sampling_ratio, stream);
 }

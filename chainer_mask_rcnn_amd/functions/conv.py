@@ -95,24 +95,27 @@ class _Conv2dFn(torch.autograd.Function):
         g = epilogue_bwd(gr, None, scale) if scale is not None else gr
         M = d.N * d.P * d.Q
         gx = gW = gb = None
+        if need_w:
+            W = ctx.W_param
+            if _direct_grad(W) and USE_WGRAD_STREAM:
+                gW = _wgrad_raw(d, x, g, W, None, None, wgrad_stream(gy.device))
+            else:
+                direct = _direct_grad(W)
+                if direct:
+                    gWt = W.grad
+                elif W.dim() == 4:
+                    gWt = empty_nhwc(tuple(W.shape), gy.device)
+                else:
+                    gWt = torch.empty_like(W)
+                ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
+                                    gy.device, 'wgrad')
+                _lib.call('mrcnn_conv2d_wgrad', ctx_desc(d), _lib.ptr(x), _lib.ptr(g),
+                          _lib.ptr(gWt), _lib.ptr(ws), _lib.stream_ptr())
+                gW = None if direct else gWt
         if need_x:
             gx = empty_nhwc((d.N, d.C, d.H, d.W), gy.device)
             _lib.call('mrcnn_conv2d_dgrad', ctx_desc(d), _lib.ptr(g), _lib.ptr(Wc), _lib.ptr(gx),
                       0, _lib.stream_ptr())
-        if need_w:
-            W = ctx.W_param
-            direct = _direct_grad(W)
-            if direct:
-                gWt = W.grad
-            elif W.dim() == 4:
-                gWt = empty_nhwc(tuple(W.shape), gy.device)
-            else:
-                gWt = torch.empty_like(W)
-            ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
-                                gy.device, 'wgrad')
-            _lib.call('mrcnn_conv2d_wgrad', ctx_desc(d), _lib.ptr(x), _lib.ptr(g),
-                      _lib.ptr(gWt), _lib.ptr(ws), _lib.stream_ptr())
-            gW = None if direct else gWt
         if need_b:
             b = ctx.b_param
             direct = _direct_grad(b)
@@ -239,6 +242,11 @@ def linear(x, W, b=None):
 # dgrad epilogue, so there is no elementwise pass and no gradient-accumulation kernel.
 # ---------------------------------------------------------------------------------------
 
+# Measured on MI355X (round 1): queueing wgrads on a second stream did not overlap with the
+# dgrads in practice (68.9 vs 68.1 ms per step), so the single-stream order is the default.
+USE_WGRAD_STREAM = False
+
+
 def _fwd_raw(x, Wc, d, scale, shift, residual, relu):
     flags = (EPI_AFFINE if scale is not None else 0) | (EPI_RESIDUAL if residual is not None else 0) \
         | (EPI_RELU if relu else 0)
@@ -256,10 +264,47 @@ def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, acc
     return gx
 
 
-def _wgrad_raw(d, x, g, W, mask_y, in_scale):
-    """Returns the tensor autograd should see for W (None when written in place)."""
+# ---- weight-gradient side stream -----------------------------------------------------------
+# dgrad and wgrad of a convolution are independent given the incoming gradient.  The wgrad
+# launches of a bottleneck go to a second HIP stream so that their workgroups fill the CUs
+# that the tail round of the concurrently running dgrad leaves idle (and vice versa): with
+# 128x128 tiles and 512 resident workgroups a single kernel wastes up to a round at its end.
+_side_streams = {}
+
+
+def wgrad_stream(device):
+    key = str(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def join_wgrad_stream(device=None):
+    """Make the current stream wait for every weight gradient queued on the side stream
+    (call before reading gradients: optimizer step, all-reduce)."""
+    for key, st in _side_streams.items():
+        if device is None or key == str(device):
+            torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+def _wgrad_raw(d, x, g, W, mask_y, in_scale, side=None):
+    """Returns the tensor autograd should see for W (None when written in place).  With
+    ``side`` (a stream) the launch is queued there, ordered after everything queued so far
+    on the current stream; only arena-backed (direct) gradients may use it."""
     direct = _direct_grad(W)
     gW = W.grad if direct else empty_nhwc(tuple(W.shape), g.device)
+    if side is not None and direct:
+        side.wait_stream(torch.cuda.current_stream(g.device))
+        for t in (x, g, mask_y):
+            if t is not None:
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
+                                g.device, 'wgrad-side')
+            _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(g),
+                      _lib.ptr(gW), _lib.ptr(ws), _lib.ptr(mask_y), _lib.ptr(in_scale),
+                      _lib.stream_ptr())
+        return None
     ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
                         g.device, 'wgrad')
     _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(g), _lib.ptr(gW),
@@ -298,17 +343,19 @@ class _BottleneckFn(torch.autograd.Function):
         gy = nhwc(gy)
         ng = ctx.needs_input_grad
         gW1 = gW2 = gW3 = gW4 = gx = None
-        # conv3 <- relu/affine(bn3) of the block output
-        gh2 = _dgrad_raw(d3, gy, nhwc(W3), y, s3)
+        side = wgrad_stream(gy.device) if USE_WGRAD_STREAM else None
+        # conv3 <- relu/affine(bn3) of the block output; each wgrad is queued on the side
+        # stream right after the dgrad that produces its incoming gradient
         if ng[7]:
-            gW3 = _wgrad_raw(d3, h2, gy, W3, y, s3)
-        gh1 = _dgrad_raw(d2, gh2, nhwc(W2), h2, s2)
-        if ng[4]:
-            gW2 = _wgrad_raw(d2, h1, gh2, W2, h2, s2)
-        if ng[1]:
-            gW1 = _wgrad_raw(d1, x, gh1, W1, h1, s1)
+            gW3 = _wgrad_raw(d3, h2, gy, W3, y, s3, side)
         if W4 is not None and ng[10]:
-            gW4 = _wgrad_raw(d4, x, gy, W4, y, s4)
+            gW4 = _wgrad_raw(d4, x, gy, W4, y, s4, side)
+        gh2 = _dgrad_raw(d3, gy, nhwc(W3), y, s3)
+        if ng[4]:
+            gW2 = _wgrad_raw(d2, h1, gh2, W2, h2, s2, side)
+        gh1 = _dgrad_raw(d2, gh2, nhwc(W2), h2, s2)
+        if ng[1]:
+            gW1 = _wgrad_raw(d1, x, gh1, W1, h1, s1, side)
         if ng[0]:
             if W4 is None:
                 # identity shortcut: gx = dgrad(conv1) + gy * (y > 0), added in the epilogue

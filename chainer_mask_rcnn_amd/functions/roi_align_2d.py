@@ -15,41 +15,44 @@ from ._layout import nhwc, empty_nhwc
 class _ROIAlign2DFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, rois, outh, outw, spatial_scale, sampling_ratio):
+    def forward(ctx, x, rois, outh, outw, spatial_scale, sampling_ratio, bin_stride=1):
         _lib.require_device(x, rois)
         x = nhwc(x)
         rois = rois.contiguous()
         N, C, H, W = x.shape
         R = rois.shape[0]
-        y = empty_nhwc((R, C, outh, outw), x.device)
-        _lib.call('mrcnn_roi_align_fwd', _lib.ptr(x), _lib.ptr(rois), _lib.ptr(y),
-                  N, H, W, C, R, outh, outw, spatial_scale, sampling_ratio,
+        oh = (outh + bin_stride - 1) // bin_stride
+        ow = (outw + bin_stride - 1) // bin_stride
+        y = empty_nhwc((R, C, oh, ow), x.device)
+        _lib.call('mrcnn_roi_align_fwd_ex', _lib.ptr(x), _lib.ptr(rois), _lib.ptr(y),
+                  N, H, W, C, R, outh, outw, bin_stride, spatial_scale, sampling_ratio,
                   _lib.stream_ptr())
         # only rois are retained (roi_align_2d.py:62-63 retain_inputs((1,)))
         ctx.save_for_backward(rois)
         ctx.x_shape = (N, C, H, W)
-        ctx.args = (outh, outw, spatial_scale, sampling_ratio)
+        ctx.args = (outh, outw, spatial_scale, sampling_ratio, bin_stride)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         rois, = ctx.saved_tensors
         N, C, H, W = ctx.x_shape
-        outh, outw, spatial_scale, sampling_ratio = ctx.args
+        outh, outw, spatial_scale, sampling_ratio, bin_stride = ctx.args
         gy = nhwc(gy)
         gx = empty_nhwc((N, C, H, W), gy.device)
-        _lib.call('mrcnn_roi_align_bwd', _lib.ptr(gy), _lib.ptr(rois), _lib.ptr(gx),
-                  N, H, W, C, rois.shape[0], outh, outw, spatial_scale,
+        _lib.call('mrcnn_roi_align_bwd_ex', _lib.ptr(gy), _lib.ptr(rois), _lib.ptr(gx),
+                  N, H, W, C, rois.shape[0], outh, outw, bin_stride, spatial_scale,
                   sampling_ratio, _lib.stream_ptr())
         # no gradient w.r.t. rois (roi_align_2d.py:389, :524)
-        return gx, None, None, None, None, None
+        return gx, None, None, None, None, None, None
 
 
 class ROIAlign2D(object):
 
     """ROI align over a set of 2d planes (reference: roi_align_2d.py:25-47)."""
 
-    def __init__(self, outh, outw, spatial_scale, sampling_ratio=0):
+    def __init__(self, outh, outw, spatial_scale, sampling_ratio=0, bin_stride=1):
+        self.bin_stride = int(bin_stride)
         for arg, value in (('outh', outh), ('outw', outw),
                            ('sampling_ratio', sampling_ratio)):
             if not (isinstance(value, int) and not isinstance(value, bool)
@@ -79,19 +82,23 @@ class ROIAlign2D(object):
     def __call__(self, x, rois):
         self.check_type_forward(x, rois)
         return _ROIAlign2DFn.apply(x, rois, self.outh, self.outw,
-                                   self.spatial_scale, self.sampling_ratio)
+                                   self.spatial_scale, self.sampling_ratio, self.bin_stride)
 
 
-def roi_align_2d(x, rois, outh, outw, spatial_scale, sampling_ratio=0, axes='xy'):
+def roi_align_2d(x, rois, outh, outw, spatial_scale, sampling_ratio=0, axes='xy',
+                 bin_stride=1):
     """Spatial Region of Interest (ROI) align function.
 
     x: (N, C, H, W) float32; rois: (R, 5) float32 rows
     ``(batch_index, x_min, y_min, x_max, y_max)`` (``axes='xy'``) or
     ``(batch_index, y_min, x_min, y_max, x_max)`` (``axes='yx'``).
     Returns (R, C, outh, outw).  Reference: roi_align_2d.py:527-560.
+
+    ``bin_stride`` (extension, default 1 = reference behaviour): produce only every
+    ``bin_stride``-th bin in each direction, i.e. exactly ``roi_align_2d(...)[:, :, ::s, ::s]``.
     """
     if axes not in ['xy', 'yx']:
         raise ValueError('Unsupported axes: {}'.format(axes))
     if axes == 'yx':
         rois = rois[:, [0, 2, 1, 4, 3]]
-    return ROIAlign2D(outh, outw, spatial_scale, sampling_ratio)(x, rois)
+    return ROIAlign2D(outh, outw, spatial_scale, sampling_ratio, bin_stride)(x, rois)

@@ -38,6 +38,7 @@ class MaskRCNNTrainChain(torch.nn.Module):
         self.loc_normalize_std = mask_rcnn.loc_normalize_std
         self.report = {}
         self.features_grad_hook = None     # set by parallel.DataParallelGradSync
+        self.mask_branch_fg_only = True
 
     def forward(self, imgs, bboxes, labels, masks, scales):
         """imgs (N,3,H,W) device tensor; bboxes / labels / masks: per-image sequences of
@@ -85,10 +86,22 @@ class MaskRCNNTrainChain(torch.nn.Module):
         sample_roi_indices = up(sample_roi_indices, torch.int32)
         gt_roi_locs = up(gt_roi_locs, torch.float32)
         gt_roi_labels = up(gt_roi_labels, torch.int32)
+        gt_roi_masks_h = gt_roi_masks
         gt_roi_masks = up(gt_roi_masks, torch.int32)
 
+        # The reference runs the mask branch on every sampled RoI (:147-148) although
+        # background rows carry all-ignored (-1) mask targets and therefore contribute
+        # neither to the loss nor to any gradient.  With
+        # ``mask_branch_fg_only`` the branch runs on the foreground rows only: identical loss
+        # (same normaliser: the count of non-ignored target pixels) and identical gradients.
+        mask_rows = None
+        if self.mask_branch_fg_only:
+            fg_rows = np.flatnonzero(np.concatenate(
+                [m.reshape(len(m), -1).max(axis=1) >= 0 for m in gt_roi_masks_h]))
+            if len(fg_rows) > 0:
+                mask_rows = torch.tensor(fg_rows, dtype=torch.int64, device=dev)
         roi_cls_locs, roi_scores, roi_masks = self.mask_rcnn.head(
-            features, sample_rois, sample_roi_indices)
+            features, sample_rois, sample_roi_indices, mask_rows=mask_rows)
 
         # RPN targets (host) — after all ProposalTargetCreator calls, as in the reference,
         # so the global np.random stream is consumed in the same order (:150-158).
@@ -114,7 +127,12 @@ class MaskRCNNTrainChain(torch.nn.Module):
         roi_cls_loss = F.softmax_cross_entropy(roi_scores, gt_roi_labels)
 
         # Losses for outputs of mask branch (:176-178)
-        roi_mask_loss = F.mask_sigmoid_cross_entropy(roi_masks, gt_roi_labels, gt_roi_masks)
+        if mask_rows is not None:
+            roi_mask_loss = F.mask_sigmoid_cross_entropy(
+                roi_masks, gt_roi_labels.index_select(0, mask_rows),
+                gt_roi_masks.index_select(0, mask_rows))
+        else:
+            roi_mask_loss = F.mask_sigmoid_cross_entropy(roi_masks, gt_roi_labels, gt_roi_masks)
 
         loss = rpn_loc_loss + rpn_cls_loss + roi_loc_loss + roi_cls_loss + roi_mask_loss
         self.report = {'rpn_loc_loss': rpn_loc_loss.detach(),

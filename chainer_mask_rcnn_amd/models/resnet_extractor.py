@@ -64,10 +64,11 @@ class Bottleneck(torch.nn.Module):
             self.conv4 = Convolution2D(in_ch, out_ch, 1, stride, 0, nobias=True)
             self.bn4 = AffineChannel2D(out_ch)
 
-    def forward(self, x):
+    def forward(self, x, stride=None):
         if self.projection:
             return F.bottleneck(x, self.conv1, self.bn1, self.conv2, self.bn2, self.conv3,
-                                self.bn3, self.conv4, self.bn4, stride=self.conv1.stride)
+                                self.bn3, self.conv4, self.bn4,
+                                stride=self.conv1.stride if stride is None else stride)
         return F.bottleneck(x, self.conv1, self.bn1, self.conv2, self.bn2, self.conv3, self.bn3)
 
     def forward_unfused(self, x):
@@ -90,9 +91,14 @@ class BuildingBlock(torch.nn.Module):
             setattr(self, name, Bottleneck(out_ch, mid_ch, out_ch))
             self._names.append(name)
 
-    def forward(self, x):
+    def forward(self, x, first_stride=None):
+        """``first_stride`` overrides the stride of block ``a`` (used by the RoI head when the
+        stride-2 subsampling has already been done by the pooling op)."""
         for name in self._names:
-            x = getattr(self, name)(x)
+            if name == 'a' and first_stride is not None:
+                x = self.a(x, stride=first_stride)
+            else:
+                x = getattr(self, name)(x)
         return x
 
 

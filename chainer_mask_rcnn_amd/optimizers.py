@@ -118,6 +118,8 @@ class MomentumSGD(object):
             if self.grad_sync is not None:
                 self.grad_sync.begin_backward()
             loss.backward()
+        from .functions.conv import join_wgrad_stream
+        join_wgrad_stream()            # weight gradients queued on the side stream
         scale = 1.0
         if self.grad_sync is not None:
             scale = self.grad_sync.finish()

@@ -101,6 +101,9 @@ class DataParallelGradSync(object):
         """Returns a tensor hook that launches bucket ``stage_index`` when fired."""
         def _hook(grad):
             if self.buckets is not None and stage_index < len(self.buckets.bounds):
+                if grad.is_cuda:
+                    from .functions.conv import join_wgrad_stream
+                    join_wgrad_stream(grad.device)   # this stage's side-stream wgrads
                 self.buckets.launch(stage_index)
             return grad
         return _hook

@@ -60,6 +60,19 @@ int mrcnn_roi_align_bwd(const float *gy, const float *rois, float *gx,
                         int N, int H, int W, int C, int R, int PH, int PW,
                         float spatial_scale, int sampling_ratio, void *stream);
 
+/* Strided-bin variants: only the bins (oh*bin_stride, ow*bin_stride) of the PH x PW grid are
+ * produced / consumed, y and gy are (R, ceil(PH/bs), ceil(PW/bs), C).  res5's first block
+ * reads the 14x14 RoI features through 1x1 stride-2 convolutions only
+ * (models/mask_rcnn_resnet.py:131-133 with roi_size // 7 == 2), i.e. it uses just the even
+ * bins; bin_stride = 2 skips the three quarters of the ROIAlign output nobody reads
+ * (identical values for the bins that are read). */
+int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *y,
+                           int N, int H, int W, int C, int R, int PH, int PW, int bin_stride,
+                           float spatial_scale, int sampling_ratio, void *stream);
+int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float *gx,
+                           int N, int H, int W, int C, int R, int PH, int PW, int bin_stride,
+                           float spatial_scale, int sampling_ratio, void *stream);
+
 /* ---- AffineChannel2D ---------------------------------------------------- */
 /* Replaces AffineChannel2DFunction.forward / backward
  * (functions/affine_channel_2d.py:10-22, :38-56).  x,y (M,C) NHWC rows,

@@ -22,6 +22,10 @@ def _rel(got, ref):
 
 @pytest.fixture(scope='module')
 def setup(dev):
+    return _build(dev)
+
+
+def _build(dev):
     torch.manual_seed(0)
     np.random.seed(0)
     model = cmr.models.MaskRCNNResNet(
@@ -177,3 +181,25 @@ def test_predict_prepared_runs(dev, setup):
         assert b.shape[1] == 4 and len(b) == len(m) == len(l) == len(s)
         assert m.shape[1:] == (80, 14, 14)
         assert len(b) <= 100
+
+
+def test_mask_branch_fg_only_is_results_identical(dev):
+    """Running the mask branch on foreground rows only gives the same losses and the same
+    parameter gradients as the reference's all-rows evaluation."""
+    model, chain, imgs, bboxes, labels, masks = _build(dev)
+    out = {}
+    for flag in (False, True):
+        for p in chain.parameters():
+            p.grad = None
+        chain.mask_branch_fg_only = flag
+        np.random.seed(321)
+        loss = chain(torch.tensor(imgs, device=dev), bboxes, labels, masks, [1., 1.])
+        loss.backward()
+        out[flag] = ({k: float(v) for k, v in chain.report.items()},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters()
+                      if p.grad is not None})
+    chain.mask_branch_fg_only = True
+    for k in out[False][0]:
+        assert abs(out[False][0][k] - out[True][0][k]) <= 1e-5 * max(abs(out[False][0][k]), 1e-3), k
+    for n, g in out[False][1].items():
+        assert _rel(out[True][1][n], g) < 1e-4, n

@@ -92,3 +92,26 @@ def test_gradient_mass_full_size_property(dev):
     s_gx = x.grad.double().sum().item()
     s_gy = gy.double().sum().item()
     assert abs(s_gx - s_gy) <= 1e-4 * gy.double().abs().sum().item()
+
+
+@pytest.mark.parametrize('C', [8, 64])
+def test_bin_stride_equals_subsampled_full(dev, C):
+    """bin_stride=2 == the even bins of the full 14x14 ROIAlign, forward (bit-exact) and
+    backward (the gradient of the subsampled output)."""
+    rng = np.random.RandomState(C)
+    N, H, W, R = 2, 25, 38, 30
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    y1 = rng.uniform(0, H * 16, R); x1 = rng.uniform(0, W * 16, R)
+    y2 = np.minimum(y1 + rng.uniform(0, 300, R), H * 16); x2 = np.minimum(x1 + rng.uniform(0, 400, R), W * 16)
+    rois = np.stack([rng.randint(0, N, R), x1, y1, x2, y2], 1).astype(np.float32)
+    xt = torch.tensor(x, device=dev, requires_grad=True)
+    ys = F.roi_align_2d(xt, torch.tensor(rois, device=dev), 14, 14, 1 / 16., bin_stride=2)
+    assert tuple(ys.shape) == (R, C, 7, 7)
+    y_ref = oracle.roi_align_fwd(x, rois, 14, 14, 1 / 16., 0)
+    assert np.array_equal(ys.detach().cpu().numpy(), y_ref[:, :, ::2, ::2])
+    gy = rng.standard_normal((R, C, 7, 7)).astype(np.float32)
+    ys.backward(torch.tensor(gy, device=dev))
+    gy_full = np.zeros((R, C, 14, 14), np.float32)
+    gy_full[:, :, ::2, ::2] = gy
+    gx_ref = oracle.roi_align_bwd(gy_full, rois, x.shape, 1 / 16., 0)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), gx_ref, rtol=1e-4, atol=1e-4)
