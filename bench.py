@@ -117,6 +117,31 @@ def profile_summary():
     return out
 
 
+def pmc_traffic(kernel_name):
+    """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary
+    (profiles/*_pmc_fetch_write.json: separate FETCH_SIZE and WRITE_SIZE passes over this
+    same command; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM: gfx950
+    tallies 128-B requests at 64 B for wide coalesced reads).  None if no summary exists."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_fetch_write.json')))
+    if not files:
+        return None
+    m = re.match(r'conv_gemm_kernel<(\d),(\d),(\w+)>', kernel_name)
+    if not m:
+        return None
+    mode = {'FWD': 0, 'DGRAD': 1, 'WGRAD': 2}[m.group(3)]
+    key = 'conv_gemm_kernel<%s, %s, %d>' % (m.group(1), m.group(2), mode)
+    with open(files[-1]) as f:
+        data = json.load(f)
+    for k, v in data.items():
+        if key in k and v.get('WRITE_SIZE_KB_per_launch') is not None:
+            return dict(bytes_per_launch=round((2.0 * v['FETCH_SIZE_KB_per_launch'] +
+                                                v['WRITE_SIZE_KB_per_launch']) * 1024.0),
+                        source=os.path.basename(files[-1]))
+    return None
+
+
 def cpu_baseline(seconds_budget=20.0):
     """Oracle ("port") timed on the host cores on a bounded sample of the same workload:
     forward + dgrad + wgrad of one res5 bottleneck (b1: 1x1 2048->512, 3x3 512->512,
@@ -160,6 +185,70 @@ def cpu_baseline(seconds_budget=20.0):
                         '~1e3 s per image' % (R, reps, dt, gflops, os.cpu_count())))
 
 
+def bench_infer(args, device, rank):
+    """BASELINE configs[4]: ResNet50-C4 inference, batch 8 x 1024 x 1024, 1000 proposals/img,
+    per-class NMS + mask head on the <= 100 detections/img (MaskRCNN.predict minus the host
+    cv2 prepare/paste, models/mask_rcnn.py:311-335)."""
+    import chainer_mask_rcnn_amd as cmr
+    from chainer_mask_rcnn_amd import _lib
+    torch.manual_seed(0)
+    batch = 8 if args.batch == 2 else args.batch
+    H = W = 1024
+    model = cmr.models.MaskRCNNResNet(
+        n_layers=args.layers, n_fg_class=80, min_size=800, max_size=1333,
+        anchor_scales=(2, 4, 8, 16, 32), roi_size=14).to(device)
+    stabilise_synthetic_weights(model)
+    with torch.no_grad():
+        # random-init class scores are ~uniform (p = 1/81 < score_thresh): sharpen them so the
+        # synthetic run produces detections for the NMS / mask stages to work on
+        model.head.cls_loc_score.W[4 * 81:5 * 81] *= 60.
+    rng = np.random.RandomState(0)
+    mean = np.asarray(MEAN, np.float32)[:, None, None]
+    x = torch.tensor(rng.uniform(0, 255, (batch, 3, H, W)).astype(np.float32) - mean,
+                     device=device).contiguous(memory_format=torch.channels_last)
+    scales = [1.6] * batch
+    sizes = [(640, 640)] * batch
+
+    def step():
+        return model.predict_prepared(x, scales, sizes)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    lib = _lib.load()
+    lib.mrcnn_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = profile_summary()
+    lib.mrcnn_profile_enable(0)
+    n_det = [len(b) for b in out[0]]
+    if rank == 0:
+        conv = {k: v for k, v in prof.items() if k.startswith('conv_gemm')}
+        gflop = sum(v['flops'] for v in conv.values()) / 1e9
+        ms = sum(v['total_ms'] for v in conv.values())
+        print(json.dumps(dict(
+            metric='images/sec inference, ResNet%d-C4 Mask R-CNN, 8x1024x1024' % args.layers,
+            value=round(args.steps * batch / elapsed, 3), unit='images/sec', n_gpus=1,
+            steps=args.steps, warmup=args.warmup,
+            ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
+            scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+            config=dict(workload='BASELINE configs[4]: ResNet%d-C4 inference, batch %dx%dx%d, '
+                        '1000 proposals/img, per-class NMS + mask head' % (args.layers, batch, H, W),
+                        detections_per_image=n_det,
+                        executed_gemm_gflop_per_image=round(gflop / args.steps / batch, 1),
+                        gemm_tflops=round(gflop / ms, 2)),
+            roofline=dict(bound='mfma', kernel='conv_gemm_kernel (all instantiations)',
+                          achieved=round(gflop / ms, 2), peak=FP32_MFMA_PEAK_TFLOPS,
+                          unit='TFLOP/s', frac=round(gflop / ms / FP32_MFMA_PEAK_TFLOPS, 4),
+                          traffic=None,
+                          kernels={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
+                                           launches_per_step=v['launches'] / args.steps)
+                                   for k, v in prof.items()}))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -171,6 +260,9 @@ def main():
     ap.add_argument('--width', type=int, default=1333)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--workload', default='train', choices=['train', 'infer'],
+                    help="'train' = BASELINE configs[1..3] (the headline metric); 'infer' = "
+                         "configs[4]: inference-only 8x1024x1024, 1000 proposals/img")
     ap.add_argument('--force-dp', action='store_true',
                     help='create a 1-rank RCCL group and run the data-parallel gradient path')
     args = ap.parse_args()
@@ -189,6 +281,9 @@ def main():
         raise SystemExit('bench.py needs a ROCm device; there is no CPU path')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+
+    if args.workload == 'infer':
+        return bench_infer(args, device, rank)
 
     # examples/train_common.py:135-136 — the samplers consume the global NumPy stream
     import random
@@ -235,6 +330,8 @@ def main():
         global_batch = args.batch * world
         value = args.steps * global_batch / elapsed
         roofline = None
+        gemm_gflop = sum(v['flops'] for k, v in prof.items() if k.startswith('conv_gemm')) / 1e9
+        gemm_ms = sum(v['total_ms'] for k, v in prof.items() if k.startswith('conv_gemm'))
         if prof:
             conv = {k: v for k, v in prof.items() if k.startswith('conv_gemm')}
             name = max(conv, key=lambda k: conv[k]['total_ms'])
@@ -242,7 +339,8 @@ def main():
             ach = d['flops'] / (d['total_ms'] * 1e-3) / 1e12
             roofline = dict(bound='mfma', kernel=name, achieved=round(ach, 2),
                             peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                            frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                            frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                            traffic=pmc_traffic(name),
                             avg_launch_us=round(d['total_ms'] * 1e3 / d['launches'], 2),
                             launches_per_step=d['launches'] / args.steps,
                             kernels={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
@@ -263,8 +361,13 @@ def main():
                         % (args.layers, args.batch, args.height, args.width, n_rois),
                         global_batch=global_batch, rois_per_image=n_rois // args.batch,
                         parallelism='dp%d' % world, loss=round(loss_val, 5),
-                        gflop_per_image=TRAIN_GFLOP_PER_IMAGE[args.layers],
-                        step_tflops=round(value * TRAIN_GFLOP_PER_IMAGE[args.layers] / 1e3 / world, 2)),
+                        # reference algorithm (mask branch on all 512 RoIs/img)
+                        reference_gflop_per_image=TRAIN_GFLOP_PER_IMAGE[args.layers],
+                        # what the GEMM kernels executed (the mask branch runs on foreground
+                        # RoIs only: identical loss and gradients)
+                        executed_gemm_gflop_per_image=round(gemm_gflop / args.steps / args.batch, 1)
+                        if prof else None,
+                        gemm_tflops=round(gemm_gflop / gemm_ms, 2) if prof else None),
             roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

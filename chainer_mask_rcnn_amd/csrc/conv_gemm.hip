@@ -31,7 +31,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
+#ifndef MRCNN_GEMM_BK
+#define MRCNN_GEMM_BK 32
+#endif
+constexpr int BK = MRCNN_GEMM_BK;
 #ifndef MRCNN_GEMM_SETPRIO
 #define MRCNN_GEMM_SETPRIO 0
 #endif
@@ -152,12 +155,13 @@ conv_gemm_kernel(const GemmParams p)
     const int n0 = (tile % ntn) * BN;
 
     // ---------------- per-thread gather state -----------------------------------
-    const int kc_row = tid >> 3, kc_c4 = tid & 7;
+    constexpr int KC_C4 = BK / 4, KC_RPP = 256 / KC_C4;   // float4 per row, rows per pass
+    const int kc_row = tid / KC_C4, kc_c4 = tid % KC_C4;
     int a_n[AV], a_y[AV], a_x[AV];     // FWD/DGRAD: pixel coords of each A row
     if (MODE != WGRAD) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            const int m = m0 + kc_row + 32 * i;
+            const int m = m0 + kc_row + KC_RPP * i;
             const bool ok = m < p.M;
             const int mm = ok ? m : 0;
             const int n = mm / (p.gp * p.gq);
@@ -220,7 +224,7 @@ conv_gemm_kernel(const GemmParams p)
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
                 int iy, ix;
-                if (MODE == FWD) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? kc_c4 : 0); }
+                if (MODE == FWD) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? (cc >> 2) : 0); }
                 else { iy = a_y[i] - r; ix = a_x[i] - s; }
                 const bool ok = c_ok && (unsigned)iy < (unsigned)p.sh && (unsigned)ix < (unsigned)p.sw;
                 const unsigned off =
@@ -235,7 +239,7 @@ conv_gemm_kernel(const GemmParams p)
             if (MODE == FWD) {
 #pragma unroll
                 for (int i = 0; i < BV; ++i) {
-                    const int n = n0 + kc_row + 32 * i;
+                    const int n = n0 + kc_row + KC_RPP * i;
                     const bool ok = n < p.N && cc < p.Kc;
                     rb[i] = bload4(rB, ok ? 4u * (unsigned)(n * p.ldb + rs * p.Kc + cc) : kOOB);
                 }
@@ -291,14 +295,14 @@ conv_gemm_kernel(const GemmParams p)
             if (HAS_MASK && use_mask) v = relu_mask(v, rm[i]);
             if (HAS_MASK && use_scale) v = mul4(v, rscale);
             if (C_::A_KC)
-                *reinterpret_cast<float4 *>(sa + (kc_row + 32 * i) * (BK + KPAD) + kc_c4 * 4) = v;
+                *reinterpret_cast<float4 *>(sa + (kc_row + KC_RPP * i) * (BK + KPAD) + kc_c4 * 4) = v;
             else
                 *reinterpret_cast<float4 *>(sa + (wa_k + A_RPP * i) * BM + wa_c4 * 4) = v;
         }
         if (C_::B_KC) {
 #pragma unroll
             for (int i = 0; i < BV; ++i)
-                *reinterpret_cast<float4 *>(sb + (kc_row + 32 * i) * (BK + KPAD) + kc_c4 * 4) = rb[i];
+                *reinterpret_cast<float4 *>(sb + (kc_row + KC_RPP * i) * (BK + KPAD) + kc_c4 * 4) = rb[i];
         } else {
 #pragma unroll
             for (int i = 0; i < BV; ++i)

@@ -151,7 +151,16 @@ class MaskRCNN(torch.nn.Module):
                 h = self.extractor(x)
                 rpn_locs, rpn_scores, rois, roi_indices, anchor = self.rpn(
                     h, x.shape[2:], scales)
-                roi_cls_locs, roi_scores, _ = self.head(h, rois, roi_indices, pred_mask=False)
+                # one image's proposals at a time: keeps every activation below the 2 GiB
+                # buffer-addressing limit of the conv kernels (8 x 1000 RoIs would not fit)
+                locs, scs = [], []
+                for i in range(x.shape[0]):
+                    sel = roi_indices == i
+                    l_i, s_i, _ = self.head(h, rois[sel], roi_indices[sel], pred_mask=False)
+                    locs.append(l_i)
+                    scs.append(s_i)
+                roi_cls_locs = torch.cat(locs, dim=0)
+                roi_scores = torch.cat(scs, dim=0)
             bboxes, labels, scores = self._to_bboxes(
                 roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales)
             roi_indices = np.concatenate(
