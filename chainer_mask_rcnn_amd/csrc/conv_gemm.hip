@@ -101,6 +101,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
 }
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
 {
+#ifdef MRCNN_DBG_NOLOAD   // experiment: every staged load hits the out-of-range path
+    off = kOOB;
+#endif
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
                        __uint_as_float(v.w));
@@ -123,8 +126,11 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
     return make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
 }
 
+#ifndef MRCNN_GEMM_MINWAVES
+#define MRCNN_GEMM_MINWAVES 1
+#endif
 template <int TM, int TN, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MRCNN_GEMM_MINWAVES)
 conv_gemm_kernel(const GemmParams p)
 {
     using C_ = Cfg<TM, TN, MODE>;

@@ -70,24 +70,29 @@ class MaskRCNNTrainChain(torch.nn.Module):
         # proposal targets: host-side sampling, exactly as the reference (:126-146)
         rois_h = rois.cpu().numpy()
         roi_indices_h = roi_indices.cpu().numpy()
+        ptc = self.proposal_target_creator
+        split = hasattr(ptc, 'sample') and hasattr(ptc, 'mask_targets')
         sample_rois, sample_roi_indices = [], []
-        gt_roi_locs, gt_roi_labels, gt_roi_masks = [], [], []
+        gt_roi_locs, gt_roi_labels, gt_roi_masks, mask_jobs = [], [], [], []
         for batch_index, (bbox, label, mask) in enumerate(zip(bboxes, labels, masks)):
             roi = rois_h[roi_indices_h == batch_index]
-            sample_roi, gt_roi_loc, gt_roi_label, gt_roi_mask = \
-                self.proposal_target_creator(roi, bbox, label, to_np(mask))
+            if split:
+                sample_roi, gt_roi_loc, gt_roi_label, job = ptc.sample(roi, bbox, label)
+                mask_jobs.append((job, mask))
+            else:
+                sample_roi, gt_roi_loc, gt_roi_label, gt_roi_mask = \
+                    ptc(roi, bbox, label, to_np(mask))
+                gt_roi_masks.append(gt_roi_mask)
             sample_rois.append(sample_roi)
             sample_roi_indices.append(np.full((len(sample_roi),), batch_index, dtype=np.int32))
             gt_roi_locs.append(gt_roi_loc)
             gt_roi_labels.append(gt_roi_label)
-            gt_roi_masks.append(gt_roi_mask)
         up = lambda parts, dt: torch.tensor(np.concatenate(parts, axis=0), dtype=dt, device=dev)
+        gt_roi_labels_h = np.concatenate(gt_roi_labels, axis=0)
         sample_rois = up(sample_rois, torch.float32)
         sample_roi_indices = up(sample_roi_indices, torch.int32)
         gt_roi_locs = up(gt_roi_locs, torch.float32)
         gt_roi_labels = up(gt_roi_labels, torch.int32)
-        gt_roi_masks_h = gt_roi_masks
-        gt_roi_masks = up(gt_roi_masks, torch.int32)
 
         # The reference runs the mask branch on every sampled RoI (:147-148) although
         # background rows carry all-ignored (-1) mask targets and therefore contribute
@@ -96,12 +101,16 @@ class MaskRCNNTrainChain(torch.nn.Module):
         # (same normaliser: the count of non-ignored target pixels) and identical gradients.
         mask_rows = None
         if self.mask_branch_fg_only:
-            fg_rows = np.flatnonzero(np.concatenate(
-                [m.reshape(len(m), -1).max(axis=1) >= 0 for m in gt_roi_masks_h]))
+            fg_rows = np.flatnonzero(gt_roi_labels_h > 0)
             if len(fg_rows) > 0:
                 mask_rows = torch.tensor(fg_rows, dtype=torch.int64, device=dev)
         roi_cls_locs, roi_scores, roi_masks = self.mask_rcnn.head(
             features, sample_rois, sample_roi_indices, mask_rows=mask_rows)
+
+        # the head is now queued on the GPU: build the 14x14 mask targets on the host meanwhile
+        if split:
+            gt_roi_masks = [ptc.mask_targets(job, to_np(mask)) for job, mask in mask_jobs]
+        gt_roi_masks = up(gt_roi_masks, torch.int32)
 
         # RPN targets (host) — after all ProposalTargetCreator calls, as in the reference,
         # so the global np.random stream is consumed in the same order (:150-158).

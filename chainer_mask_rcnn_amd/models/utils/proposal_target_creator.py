@@ -31,6 +31,16 @@ class ProposalTargetCreator(object):
         """roi (R,4), bbox (G,4), label (G,), mask (G,H,W) host arrays ->
         sample_roi (S,4) f32, gt_roi_loc (S,4) f32, gt_roi_label (S,) i32 (0 = bg),
         gt_roi_mask (S,14,14) i32 in {-1,0,1}."""
+        sample_roi, gt_roi_loc, gt_roi_label, job = self.sample(
+            roi, bbox, label, loc_normalize_mean, loc_normalize_std)
+        return sample_roi, gt_roi_loc, gt_roi_label, self.mask_targets(job, mask)
+
+    def sample(self, roi, bbox, label, loc_normalize_mean=(0., 0., 0., 0.),
+               loc_normalize_std=(0.1, 0.1, 0.2, 0.2)):
+        """Everything that consumes ``np.random`` (and everything the RoI head needs before it
+        can be launched): the sampled RoIs, their regression targets and labels, plus an
+        opaque job for ``mask_targets``.  The train chain launches the head on the GPU right
+        after this and builds the 14x14 mask targets on the host meanwhile."""
         roi = np.asarray(roi, np.float32)
         bbox = np.asarray(bbox, np.float32)
         label = np.asarray(label)
@@ -64,15 +74,19 @@ class ProposalTargetCreator(object):
         gt_roi_loc = ((gt_roi_loc - np.array(loc_normalize_mean, np.float32)) /
                       np.array(loc_normalize_std, np.float32)).astype(np.float32)
 
-        # 14x14 mask targets for the foreground RoIs; background rows stay -1 (:160-177).
-        # The reference one-hot encodes the {0,1} crop, resizes both channels with
-        # bilinear weights (which sum to 1) and takes the argmax, i.e. fg prob > 0.5.
+        job = (len(sample_roi), n_fg, np.round(sample_roi[:n_fg]).astype(np.int32), assigned[fg])
+        return sample_roi, gt_roi_loc, gt_roi_label, job
+
+    def mask_targets(self, job, mask):
+        """14x14 mask targets for the foreground RoIs; background rows stay -1 (:160-177).
+        The reference one-hot encodes the {0,1} crop, resizes both channels with bilinear
+        weights (which sum to 1) and takes the argmax, i.e. foreground probability > 0.5."""
+        n, n_fg, boxes, gt_index = job
         M = self.mask_size
-        gt_roi_mask = -np.ones((len(sample_roi), M, M), dtype=np.int32)
+        gt_roi_mask = -np.ones((n, M, M), dtype=np.int32)
         if n_fg > 0:
-            gt_roi_mask[:n_fg] = _mask_targets(
-                np.round(sample_roi[:n_fg]).astype(np.int32), assigned[fg], mask, M)
-        return sample_roi, gt_roi_loc, gt_roi_label, gt_roi_mask
+            gt_roi_mask[:n_fg] = _mask_targets(boxes, gt_index, np.asarray(mask), M)
+        return gt_roi_mask
 
 
 def _mask_targets(boxes, gt_index, mask, M):
