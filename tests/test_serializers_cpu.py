@@ -1,0 +1,83 @@
+"""Chainer-compatible .npz snapshot contract: key names / shapes as filled by
+the reference's examples/coco/convert_caffe2_to_chainer.py, round trip, fused-filter split."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import chainer_mask_rcnn_amd as cmr
+from chainer_mask_rcnn_amd import serializers
+
+
+@pytest.fixture(scope='module')
+def model():
+    torch.manual_seed(0)
+    return cmr.models.MaskRCNNResNet(50, n_fg_class=80, anchor_scales=(2, 4, 8, 16, 32),
+                                     roi_size=14)
+
+
+def test_reference_parameter_names_and_shapes(model):
+    arrs = serializers.state_arrays(model)
+    expect = {
+        'extractor/conv1/W': (64, 3, 7, 7), 'extractor/conv1/b': (64,),
+        'extractor/bn1/W': (64,), 'extractor/bn1/b': (64,),
+        'extractor/res2/a/conv1/W': (64, 64, 1, 1), 'extractor/res2/a/conv4/W': (256, 64, 1, 1),
+        'extractor/res2/b2/bn3/b': (256,), 'extractor/res3/a/conv1/W': (128, 256, 1, 1),
+        'extractor/res3/b3/conv2/W': (128, 128, 3, 3), 'extractor/res4/b5/conv3/W': (1024, 256, 1, 1),
+        'rpn/conv1/W': (1024, 1024, 3, 3), 'rpn/conv1/b': (1024,),
+        'rpn/score/W': (15, 1024, 1, 1), 'rpn/score/b': (15,),
+        'rpn/loc/W': (60, 1024, 1, 1), 'rpn/loc/b': (60,),
+        'head/res5/a/conv1/W': (512, 1024, 1, 1), 'head/res5/b2/conv3/W': (2048, 512, 1, 1),
+        'head/cls_loc/W': (324, 2048), 'head/cls_loc/b': (324,),
+        'head/score/W': (81, 2048), 'head/score/b': (81,),
+        'head/deconv6/W': (2048, 256, 2, 2), 'head/deconv6/b': (256,),
+        'head/mask/W': (80, 256, 1, 1), 'head/mask/b': (80,),
+    }
+    for k, shp in expect.items():
+        assert k in arrs, k
+        assert arrs[k].shape == shp, (k, arrs[k].shape)
+        assert arrs[k].dtype == np.float32
+    assert not any('res5' in k for k in arrs if k.startswith('extractor/'))   # removed layers
+    # R-50: 53 affine sites (1 + 10 + 13 + 19 + 10), each with W and b
+    assert sum(1 for k in arrs if '/bn' in k) == 2 * 53
+
+
+def test_roundtrip_and_fused_split(model, tmp_path):
+    path = os.path.join(str(tmp_path), 'snapshot_model.npz')
+    serializers.save_npz(path, model)
+    torch.manual_seed(1)
+    other = cmr.models.MaskRCNNResNet(50, n_fg_class=80, anchor_scales=(2, 4, 8, 16, 32),
+                                      roi_size=14)
+    serializers.load_npz(path, other)
+    for (n, a), (_, b) in zip(model.named_parameters(), other.named_parameters()):
+        if 'loc_score' in n:
+            rows = 75 if n.startswith('rpn') else 405      # padding rows are not serialised
+            assert torch.equal(a[:rows], b[:rows]), n
+        else:
+            assert torch.equal(a, b), n
+        assert a.stride() == b.stride()
+    # the views keep the reference's attribute names
+    assert torch.equal(other.rpn.loc.W, model.rpn.loc_score.W[:60])
+    assert torch.equal(other.head.score.b, model.head.cls_loc_score.b[324:405])
+
+
+def test_load_rejects_wrong_shapes(model, tmp_path):
+    arrs = serializers.state_arrays(model)
+    arrs['head/mask/W'] = np.zeros((20, 256, 1, 1), np.float32)     # a VOC-sized snapshot
+    path = os.path.join(str(tmp_path), 'bad.npz')
+    np.savez(path, **arrs)
+    with pytest.raises(ValueError):
+        serializers.load_npz(path, model)
+
+
+def test_pretrained_model_argument(model, tmp_path):
+    path = os.path.join(str(tmp_path), 'm.npz')
+    serializers.save_npz(path, model)
+    m2 = cmr.models.MaskRCNNResNet(50, n_fg_class=80, pretrained_model=path,
+                                   anchor_scales=(2, 4, 8, 16, 32), roi_size=14)
+    assert torch.equal(m2.extractor.res4.b5.conv3.W, model.extractor.res4.b5.conv3.W)
+    with pytest.raises(ValueError):
+        cmr.models.MaskRCNNResNet(34, n_fg_class=80)
+    with pytest.raises(ValueError):
+        cmr.models.MaskRCNNResNet(50, n_fg_class=80, mean=(1., 2.))
