@@ -39,6 +39,10 @@ constexpr int BK = MRCNN_GEMM_BK;
 #define MRCNN_GEMM_SETPRIO 0
 #endif
 constexpr bool SETPRIO = MRCNN_GEMM_SETPRIO != 0;
+#ifndef MRCNN_GEMM_PINGPONG
+#define MRCNN_GEMM_PINGPONG 0   // measured slower than two free-running workgroups per CU
+#endif
+constexpr bool USE_PINGPONG = MRCNN_GEMM_PINGPONG != 0;
 constexpr int KPAD = 4;  // K-contiguous LDS rows are 36 floats (conflict-free b128)
 
 enum Mode { FWD = 0, DGRAD = 1, WGRAD = 2 };
@@ -129,17 +133,28 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
 #ifndef MRCNN_GEMM_MINWAVES
 #define MRCNN_GEMM_MINWAVES 1
 #endif
-template <int TM, int TN, int MODE>
-__global__ void __launch_bounds__(256, MRCNN_GEMM_MINWAVES)
+// PP ("ping-pong"): a 512-thread workgroup runs TWO independent output tiles, one per group of
+// four waves, in antiphase: while one group issues its 64 MFMAs per K slice the other group
+// does everything else (wait for its global loads, write them to LDS, issue the next loads),
+// then they swap at a workgroup barrier.  Each SIMD hosts one wave of either group, so its
+// MFMA pipe always has exactly one wave feeding it and never waits for staging work; with two
+// free-running 256-thread workgroups per CU the pipe measured ~80 % busy.
+// Measured on MI355X (round 1): the strict antiphase is SLOWER (res5 3x3 fwd 110 vs 122 TF/s):
+// one wave per SIMD cannot keep the fp32 MFMA pipe as full as two interleaved waves do.  Kept
+// as a compile-time experiment (-DMRCNN_GEMM_PINGPONG=1), off by default.
+template <int TM, int TN, int MODE, bool PP>
+__global__ void __launch_bounds__(PP ? 512 : 256, MRCNN_GEMM_MINWAVES)
 conv_gemm_kernel(const GemmParams p)
 {
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
     constexpr int AV = C_::A_V4, BV = C_::B_V4;
     constexpr bool HAS_MASK = (MODE != FWD);
-    __shared__ __attribute__((aligned(16))) float smem[2][C_::A_FLOATS + C_::B_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem_all[PP ? 2 : 1][2][C_::A_FLOATS + C_::B_FLOATS];
 
-    const int tid = threadIdx.x;
+    const int grp = PP ? (int)(threadIdx.x >> 8) : 0;   // ping-pong group (wave-uniform)
+    float (*smem)[C_::A_FLOATS + C_::B_FLOATS] = smem_all[grp];
+    const int tid = threadIdx.x & 255;                  // thread index within the group
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -157,6 +172,7 @@ conv_gemm_kernel(const GemmParams p)
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    if (PP) tile = 2 * tile + grp;   // a surplus tile lies beyond M: all its accesses are OOB
     const int m0 = p.m_lo + (tile / ntn) * BM;
     const int n0 = (tile % ntn) * BN;
 
@@ -398,13 +414,33 @@ conv_gemm_kernel(const GemmParams p)
         load_slice(0);
         store_slice(0);
     }
-    __syncthreads();
-    for (int kt = 0; kt < nslices; ++kt) {
-        const bool more = kt + 1 < nslices;
-        if (more) load_slice(kt + 1);
-        compute(kt & 1);
-        if (more) store_slice((kt + 1) & 1);
+    if (PP) {
+        // half-steps: group g computes slice kt at h = g + 2*kt and stages at h = g + 2*kt + 1
+        if (nslices > 1) load_slice(1);
         __syncthreads();
+        const int nh = 2 * nslices + 1;
+        for (int h = 0; h < nh; ++h) {
+            const int hh = h - grp;
+            if (hh >= 0 && hh < 2 * nslices) {
+                const int kt = hh >> 1;
+                if ((hh & 1) == 0) {
+                    compute(kt & 1);
+                } else {
+                    if (kt + 1 < nslices) store_slice((kt + 1) & 1);
+                    if (kt + 2 < nslices) load_slice(kt + 2);
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (int kt = 0; kt < nslices; ++kt) {
+            const bool more = kt + 1 < nslices;
+            if (more) load_slice(kt + 1);
+            compute(kt & 1);
+            if (more) store_slice((kt + 1) & 1);
+            __syncthreads();
+        }
     }
 
     // ---------------- epilogue ------------------------------------------------------
@@ -511,6 +547,18 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, i
 constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
 
 template <int TM, int TN, int MODE>
+void launch_kernel(const GemmParams &p, int64_t tiles, int splits, hipStream_t s)
+{
+    if constexpr (TM == 2 && USE_PINGPONG) {
+        hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, true>),
+                           dim3((unsigned)mrcnn::ceil_div(tiles, 2), splits), dim3(512), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, false>), dim3((unsigned)tiles, splits),
+                           dim3(256), 0, s, p);
+    }
+}
+
+template <int TM, int TN, int MODE>
 void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
 {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -525,8 +573,7 @@ void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
     mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
                               (TM == 2 ? 0 : 1),
                           flops, bytes, s);
-    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE>), dim3((unsigned)blocks, splits), dim3(256), 0,
-                       s, p);
+    launch_kernel<TM, TN, MODE>(p, blocks, splits, s);
 }
 
 // FWD / DGRAD launch policy.  With T 128x128 tiles and 512 resident workgroups a launch
@@ -738,13 +785,10 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     mrcnn::ProfScope prof(use_big ? mrcnn::PROF_CONV_WGRAD_128 : mrcnn::PROF_CONV_WGRAD_64,
                           2.0 * p.M * p.N * (double)pixels,
                           4.0 * ((double)p.M * p.N + (double)pixels * (p.M + (double)C)), s);
-    if (use_big) {
-        hipLaunchKernelGGL((conv_gemm_kernel<2, 2, WGRAD>), dim3((unsigned)big, splits), dim3(256), 0,
-                           s, p);
-    } else {
-        hipLaunchKernelGGL((conv_gemm_kernel<1, 1, WGRAD>), dim3((unsigned)tiles, splits), dim3(256),
-                           0, s, p);
-    }
+    if (use_big)
+        launch_kernel<2, 2, WGRAD>(p, big, splits, s);
+    else
+        launch_kernel<1, 1, WGRAD>(p, tiles, splits, s);
     if (splits > 1) {
         int64_t blocks = mrcnn::ceil_div(gwsz / 4, 256);
         if (blocks > 4096) blocks = 4096;

@@ -32,7 +32,7 @@ hipEvent_t get_event()
         return e;
     }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 }  // namespace
@@ -48,14 +48,14 @@ void prof_begin(int kind, double flops, double bytes, hipStream_t s)
     r.kind = kind;
     r.flops = flops;
     r.bytes = bytes;
-    hipEventRecord(r.start, s);
+    (void)hipEventRecord(r.start, s);
     g_prof_recs.push_back(r);
 }
 
 void prof_end(hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_recs.empty()) hipEventRecord(g_prof_recs.back().stop, s);
+    if (!g_prof_recs.empty()) (void)hipEventRecord(g_prof_recs.back().stop, s);
 }
 }  // namespace mrcnn
 

@@ -93,3 +93,71 @@ def test_arena_layout_and_stage_buckets():
     m.c.grad.fill_(2.)
     assert float(arena.grads[:96].sum()) == 192.
     assert arena.slice_bounds(0, 1) == (0, 104)
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'] = str(rank)
+    os.environ['WORLD_SIZE'] = str(world)
+    from chainer_mask_rcnn_amd import parallel, optimizers
+    parallel.init_from_env(backend='gloo')
+
+    class Blk(torch.nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            self.W = torch.nn.Parameter(torch.full((n,), float(rank + 1)))
+
+    class Ext(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.res3, self.res4 = Blk(8), Blk(12)
+            self.stage_hooks = {}
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.extractor, self.rpn, self.head = Ext(), Blk(5), Blk(20)
+
+    class Chain(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mask_rcnn = Net()
+            self.features_grad_hook = None
+
+    chain = Chain()
+    opt = optimizers.MomentumSGD(lr=0.1)
+    opt.setup(chain)
+    sync = parallel.DataParallelGradSync(opt)
+    opt._build()                                   # arena + attach (broadcast, buckets)
+    a = opt.arena
+    ok = sync.world_size == world
+    # rank-0 weights everywhere
+    ok = ok and bool((a.values[a.values != 0] == 1.0).all())
+    # buckets: head+rpn | res4 | res3, contiguous, in backward order
+    ok = ok and len(sync.buckets.bounds) == 3 and sync.buckets.bounds[0][0] == 0
+    ok = ok and sync.buckets.bounds[-1][1] == a.size
+    ok = ok and chain.features_grad_hook is not None and 'res3' in chain.mask_rcnn.extractor.stage_hooks
+    # a "backward": every rank writes rank+1 into its gradients, hooks fire in stage order
+    a.grads.fill_(float(rank + 1))
+    chain.features_grad_hook(torch.zeros(1))
+    chain.mask_rcnn.extractor.stage_hooks['res3'](torch.zeros(1))
+    scale = sync.finish()
+    ok = ok and abs(scale - 1.0 / world) < 1e-12
+    ok = ok and bool((a.grads == float(sum(range(1, world + 1)))).all())
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_grad_sync_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(2))
+    assert res == {0: True, 1: True}
