@@ -45,7 +45,11 @@ constexpr bool SETPRIO = MRCNN_GEMM_SETPRIO != 0;
 constexpr bool USE_PINGPONG = MRCNN_GEMM_PINGPONG != 0;
 constexpr int KPAD = 4;  // K-contiguous LDS rows are 36 floats (conflict-free b128)
 
-enum Mode { FWD = 0, DGRAD = 1, WGRAD = 2 };
+// FWDM = forward-form gather whose A operand carries the fused epilogue-backward (mask /
+// scale) and whose epilogue may add the shortcut gradient: the stride-1 dgrad expressed as a
+// forward convolution of gy with the flipped, transposed filter (both operands K-contiguous).
+enum Mode { FWD = 0, DGRAD = 1, WGRAD = 2, FWDM = 3 };
+constexpr bool is_fwd(int m) { return m == FWD || m == FWDM; }
 enum OutMode { OUT_PLAIN = 0, OUT_STRIDED = 1, OUT_DECONV = 2 };
 
 struct GemmParams {
@@ -83,7 +87,7 @@ template <int TM, int TN, int MODE>
 struct Cfg {
     static constexpr int BM = 64 * TM, BN = 64 * TN;
     static constexpr bool A_KC = (MODE != WGRAD);  // A K-contiguous?
-    static constexpr bool B_KC = (MODE == FWD);
+    static constexpr bool B_KC = is_fwd(MODE);
     static constexpr int A_FLOATS = A_KC ? BM * (BK + KPAD) : BK * BM;
     static constexpr int B_FLOATS = B_KC ? BN * (BK + KPAD) : BK * BN;
     static constexpr int A_V4 = BM * BK / 4 / 256;  // float4 per thread per slice
@@ -150,6 +154,7 @@ conv_gemm_kernel(const GemmParams p)
     constexpr int BM = C_::BM, BN = C_::BN;
     constexpr int AV = C_::A_V4, BV = C_::B_V4;
     constexpr bool HAS_MASK = (MODE != FWD);
+    constexpr bool FWDLIKE = is_fwd(MODE);
     __shared__ __attribute__((aligned(16))) float smem_all[PP ? 2 : 1][2][C_::A_FLOATS + C_::B_FLOATS];
 
     const int grp = PP ? (int)(threadIdx.x >> 8) : 0;   // ping-pong group (wave-uniform)
@@ -190,7 +195,7 @@ conv_gemm_kernel(const GemmParams p)
             const int rem = mm - n * (p.gp * p.gq);
             const int gy = rem / p.gq, gx = rem - gy * p.gq;
             a_n[i] = n;
-            if (MODE == FWD) { a_y[i] = gy * p.stride - p.pad; a_x[i] = gx * p.stride - p.pad; }
+            if (FWDLIKE) { a_y[i] = gy * p.stride - p.pad; a_x[i] = gx * p.stride - p.pad; }
             else { a_y[i] = gy + p.pad; a_x[i] = gx + p.pad; }
             if (!ok) a_y[i] = -(1 << 28);          // row beyond M: every tap out of range
         }
@@ -237,7 +242,7 @@ conv_gemm_kernel(const GemmParams p)
 
     // issue the global loads of slice kt (nothing here consumes a loaded value)
     auto load_slice = [&](int kt) {
-        if (MODE == FWD || MODE == DGRAD) {
+        if (FWDLIKE || MODE == DGRAD) {
             const int rs = kt / cprs;
             const int c0 = (kt - rs * cprs) * BK;
             const int r = rs / p.S, s = rs - r * p.S;
@@ -246,19 +251,19 @@ conv_gemm_kernel(const GemmParams p)
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
                 int iy, ix;
-                if (MODE == FWD) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? (cc >> 2) : 0); }
+                if (FWDLIKE) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? (cc >> 2) : 0); }
                 else { iy = a_y[i] - r; ix = a_x[i] - s; }
                 const bool ok = c_ok && (unsigned)iy < (unsigned)p.sh && (unsigned)ix < (unsigned)p.sw;
                 const unsigned off =
                     ok ? 4u * (unsigned)(((a_n[i] * p.sh + iy) * p.sw + ix) * p.lda + (p.stem ? 0 : cc))
                        : kOOB;
                 ra[i] = bload4(rA, off);
-                if (MODE == DGRAD && use_mask) rm[i] = bload4(rMask, off);
+                if (HAS_MASK && use_mask) rm[i] = bload4(rMask, off);
             }
-            if (MODE == DGRAD && use_scale)
+            if (HAS_MASK && use_scale)
                 rscale = cc < p.Kc ? *reinterpret_cast<const float4 *>(p.in_scale + cc)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (MODE == FWD) {
+            if (FWDLIKE) {
 #pragma unroll
                 for (int i = 0; i < BV; ++i) {
                     const int n = n0 + kc_row + KC_RPP * i;
@@ -455,7 +460,7 @@ conv_gemm_kernel(const GemmParams p)
     const bool f_bias = (p.flags & MRCNN_EPI_BIAS) != 0, f_aff = (p.flags & MRCNN_EPI_AFFINE) != 0;
     const bool f_res = (p.flags & MRCNN_EPI_RESIDUAL) != 0, f_relu = (p.flags & MRCNN_EPI_RELU) != 0;
     const bool f_acc = (p.flags & MRCNN_EPI_ACCUM) != 0;
-    const bool f_resg = MODE == DGRAD && p.res_g != nullptr;
+    const bool f_resg = (MODE == DGRAD || MODE == FWDM) && p.res_g != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (32 * TN) + j * 32 + li;
@@ -745,6 +750,65 @@ extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, 
             MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)d->N * d->H * d->W * d->C, s));
     }
     return launch<DGRAD>(p, 1, s);
+}
+
+namespace {
+// wT[c][R-1-r][S-1-s][k] = w[k][r][s][c]
+__global__ void filter_flip_transpose_kernel(const float *__restrict__ w, float *__restrict__ wT,
+                                             int K, int RS, int C)
+{
+    __shared__ float tile[32][33];
+    const int rs = blockIdx.z;
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int k = k0 + j, c = c0 + tx;
+        tile[j][tx] = (k < K && c < C) ? w[((int64_t)k * RS + rs) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, k = k0 + tx;
+        if (c < C && k < K) wT[((int64_t)c * RS + (RS - 1 - rs)) * K + k] = tile[tx][j];
+    }
+}
+}  // namespace
+
+extern "C" int mrcnn_filter_flip_transpose(const float *w, float *wT, int K, int R, int S, int C,
+                                           void *stream)
+{
+    MRCNN_REQUIRE(w && wT && K > 0 && R > 0 && S > 0 && C > 0, "filter_flip_transpose: bad args");
+    hipLaunchKernelGGL(filter_flip_transpose_kernel,
+                       dim3((C + 31) / 32, (K + 31) / 32, R * S), dim3(256), 0,
+                       mrcnn::as_stream(stream), w, wT, K, R * S, C);
+    return mrcnn::check_launch("filter_flip_transpose");
+}
+
+// Stride-1 dgrad as a forward-form convolution of gy with wT = flip-transpose(w) (C,R,S,K):
+// both operands are K-contiguous (ds_read_b128 fragments, coalesced filter rows).
+extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, const float *wT,
+                                     float *gx, int epi_flags, const float *mask_y,
+                                     const float *in_scale, const float *res_g,
+                                     const float *res_y, void *stream)
+{
+    if (int rc = check_desc(d)) return rc;
+    MRCNN_REQUIRE(d->stride == 1, "conv2d_dgrad_wt: stride must be 1");
+    MRCNN_REQUIRE(gy && wT && gx, "conv2d_dgrad_wt: null pointer");
+    MRCNN_REQUIRE(aligned16(gy) && aligned16(wT), "conv2d_dgrad_wt: gy/wT must be 16-byte aligned");
+    MRCNN_REQUIRE((epi_flags & ~MRCNN_EPI_ACCUM) == 0, "conv2d_dgrad_wt: only MRCNN_EPI_ACCUM is valid");
+    MRCNN_REQUIRE((res_g == nullptr) == (res_y == nullptr), "conv2d_dgrad_wt: res_g/res_y go together");
+    GemmParams p = {};
+    p.A = gy; p.B = wT; p.C = gx;
+    p.mask_y = mask_y; p.in_scale = in_scale; p.res_g = res_g; p.res_y = res_y;
+    p.M = d->N * d->H * d->W; p.N = d->C; p.Kc = d->K;
+    p.gp = d->H; p.gq = d->W; p.sh = d->P; p.sw = d->Q;
+    p.R = d->R; p.S = d->S; p.stride = 1; p.pad = d->R - 1 - d->pad;
+    p.lda = d->K; p.ldb = d->R * d->S * d->K; p.ldc = d->C;
+    p.flags = epi_flags; p.out_mode = OUT_PLAIN;
+    MRCNN_REQUIRE(d->S - 1 - d->pad == p.pad, "conv2d_dgrad_wt: square filters / symmetric padding only");
+    if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->R * d->S * d->C,
+                             (int64_t)d->N * d->H * d->W * d->C))
+        return rc;
+    return launch<FWDM>(p, 1, mrcnn::as_stream(stream));
 }
 
 extern "C" int64_t mrcnn_conv2d_wgrad_workspace_bytes(const mrcnn_conv_desc *d)

@@ -113,9 +113,7 @@ class _Conv2dFn(torch.autograd.Function):
                           _lib.ptr(gWt), _lib.ptr(ws), _lib.stream_ptr())
                 gW = None if direct else gWt
         if need_x:
-            gx = empty_nhwc((d.N, d.C, d.H, d.W), gy.device)
-            _lib.call('mrcnn_conv2d_dgrad', ctx_desc(d), _lib.ptr(g), _lib.ptr(Wc), _lib.ptr(gx),
-                      0, _lib.stream_ptr())
+            gx = _dgrad_raw(d, g, Wc, None, None)
         if need_b:
             b = ctx.b_param
             direct = _direct_grad(b)
@@ -256,8 +254,22 @@ def _fwd_raw(x, Wc, d, scale, shift, residual, relu):
     return y
 
 
+USE_TRANSPOSED_DGRAD = True
+
+
 def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, accum=False):
     gx = out if out is not None else empty_nhwc((d.N, d.C, d.H, d.W), g.device)
+    if USE_TRANSPOSED_DGRAD and d.stride == 1 and d.R == d.S:
+        # forward-form dgrad on the flipped, transposed filter (rebuilt per call: it moves
+        # 2 x the filter bytes, microseconds next to the GEMM)
+        nbytes = 4 * d.K * d.R * d.S * d.C
+        wT = _lib.workspace(nbytes, g.device, 'wT')
+        _lib.call('mrcnn_filter_flip_transpose', _lib.ptr(Wc), _lib.ptr(wT), d.K, d.R, d.S, d.C,
+                  _lib.stream_ptr())
+        _lib.call('mrcnn_conv2d_dgrad_wt', ctx_desc(d), _lib.ptr(g), _lib.ptr(wT), _lib.ptr(gx),
+                  EPI_ACCUM if accum else 0, _lib.ptr(mask_y), _lib.ptr(in_scale),
+                  _lib.ptr(res_g), _lib.ptr(res_y), _lib.stream_ptr())
+        return gx
     _lib.call('mrcnn_conv2d_dgrad_ex', ctx_desc(d), _lib.ptr(g), _lib.ptr(Wc), _lib.ptr(gx),
               EPI_ACCUM if accum else 0, _lib.ptr(mask_y), _lib.ptr(in_scale), _lib.ptr(res_g),
               _lib.ptr(res_y), _lib.stream_ptr())

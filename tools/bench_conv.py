@@ -67,6 +67,13 @@ def main():
                               _lib.ptr(gx), 0, sp)
         h = lambda: _lib.call('mrcnn_conv2d_wgrad', ctx_desc(d), _lib.ptr(x), _lib.ptr(gy),
                               _lib.ptr(gw), _lib.ptr(ws), sp)
+        if os.environ.get('BENCH_MASK'):
+            ymask = torch.randn((d.N, d.P, d.Q, d.K), device=dev).permute(0, 3, 1, 2)
+            sc = torch.rand((d.K,), device=dev) + 0.5
+            g = lambda: _lib.call('mrcnn_conv2d_dgrad_ex', ctx_desc(d), _lib.ptr(gy), _lib.ptr(w),
+                                  _lib.ptr(gx), 0, _lib.ptr(ymask), _lib.ptr(sc), None, None, sp)
+            h = lambda: _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(gy),
+                                  _lib.ptr(gw), _lib.ptr(ws), _lib.ptr(ymask), _lib.ptr(sc), sp)
         tf, tg, th = timeit(f), timeit(g), timeit(h)
         tot['fwd'] += tf; tot['dgrad'] += tg; tot['wgrad'] += th
         print('%-28s %5.1f|%5.2f %5.1f|%5.2f %5.1f|%5.2f' % (
