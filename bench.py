@@ -276,6 +276,9 @@ def main():
         dist.init_process_group('nccl', rank=0, world_size=1)
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    # one process per GPU shares the host with its peers: keep torch's CPU thread pool (used
+    # only for tiny host-side tensor plumbing) from oversubscribing the cores
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(1, 2 * world))))
     _lib.load()                                   # fail loudly without the HIP library
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device; there is no CPU path')

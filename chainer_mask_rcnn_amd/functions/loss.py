@@ -57,8 +57,11 @@ class _MaskSigmoidCEFn(torch.autograd.Function):
         R, Kc, H, W = x.shape
         loss = _scalar(x.device)
         gx = empty_nhwc((R, Kc, H, W), x.device) if roi_masks.requires_grad else None
-        _lib.call('mrcnn_mask_sigmoid_ce', _lib.ptr(x), _lib.ptr(gt_label.contiguous()),
-                  _lib.ptr(gt_mask.contiguous()), R, H * W, Kc, _lib.ptr(loss), _lib.ptr(gx),
+        # bind temporaries to names: a tensor created inside the argument list would be freed
+        # (and its block possibly re-used) before the asynchronous kernel reads it
+        gt_label, gt_mask = gt_label.contiguous(), gt_mask.contiguous()
+        _lib.call('mrcnn_mask_sigmoid_ce', _lib.ptr(x), _lib.ptr(gt_label),
+                  _lib.ptr(gt_mask), R, H * W, Kc, _lib.ptr(loss), _lib.ptr(gx),
                   _lib.ptr(_ws(x.device)), _lib.stream_ptr())
         ctx.gx = gx
         return loss
@@ -84,7 +87,8 @@ class _SoftmaxCEFn(torch.autograd.Function):
         loss = _scalar(x.device)
         gx = torch.empty((R, ncls), dtype=torch.float32, device=x.device) \
             if x.requires_grad else None
-        _lib.call('mrcnn_softmax_ce', _lib.ptr(x), x.stride(0), _lib.ptr(t.contiguous()), R,
+        t = t.contiguous()
+        _lib.call('mrcnn_softmax_ce', _lib.ptr(x), x.stride(0), _lib.ptr(t), R,
                   ncls, _lib.ptr(loss), _lib.ptr(gx), ncls, _lib.ptr(_ws(x.device, R)),
                   _lib.stream_ptr())
         ctx.gx = gx
@@ -111,13 +115,14 @@ class _SmoothL1Fn(torch.autograd.Function):
         _lib.require_device(pred, gt_loc, gt_label)
         assert pred.dim() == 2
         pc = pred.contiguous()
+        gt_loc, gt_label = gt_loc.contiguous(), gt_label.contiguous()
         n, width = pc.shape
         loss = _scalar(pred.device)
         # the kernel writes only the selected 4-vectors of rows with label > 0
         gx = torch.zeros((n, width), dtype=torch.float32, device=pred.device) \
             if pred.requires_grad else None
         _lib.call('mrcnn_smooth_l1', _lib.ptr(pc), width, _lib.ptr(cls),
-                  _lib.ptr(gt_loc.contiguous()), _lib.ptr(gt_label.contiguous()), n,
+                  _lib.ptr(gt_loc), _lib.ptr(gt_label), n,
                   float(sigma), _lib.ptr(loss), _lib.ptr(gx), _lib.ptr(_ws(pred.device)),
                   _lib.stream_ptr())
         ctx.gx = gx

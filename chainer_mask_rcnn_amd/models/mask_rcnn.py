@@ -64,7 +64,8 @@ class MaskRCNN(torch.nn.Module):
         counts = torch.empty((n_fg,), dtype=torch.int32, device=dev)
         ws = _lib.workspace(_lib.load().mrcnn_detect_sort_workspace_bytes(R, self.n_class), dev,
                             'detect')
-        _lib.call('mrcnn_detect_sort', _lib.ptr(prob.contiguous()), _lib.ptr(cls_bbox.contiguous()),
+        prob, cls_bbox = prob.contiguous(), cls_bbox.contiguous()
+        _lib.call('mrcnn_detect_sort', _lib.ptr(prob), _lib.ptr(cls_bbox),
                   R, self.n_class, float(self.score_thresh), _lib.ptr(sorted_boxes),
                   _lib.ptr(sorted_prob), _lib.ptr(counts), _lib.ptr(ws), _lib.stream_ptr())
         keep, n_keep = P.nms_sorted_batched(sorted_boxes, counts, self.nms_thresh)
@@ -121,13 +122,16 @@ class MaskRCNN(torch.nn.Module):
             scores.append(score)
         return bboxes, labels, scores
 
-    def _to_roi_masks(self, h, bboxes, roi_indices, scales):
+    def _to_roi_masks(self, h, bboxes, roi_indices, scales, to_host=True):
         batch_size = h.shape[0]
         bboxes = np.concatenate(bboxes, axis=0)
+        n_fg_class = self.n_class - 1
+        mask_size = self.head.mask_size
         if bboxes.size == 0:
-            n_fg_class = self.n_class - 1
-            mask_size = self.head.mask_size
-            return [np.zeros((0, n_fg_class, mask_size, mask_size), dtype=np.float32)
+            if to_host:
+                return [np.zeros((0, n_fg_class, mask_size, mask_size), dtype=np.float32)
+                        for _ in range(batch_size)]
+            return [torch.zeros((0, n_fg_class, mask_size, mask_size), device=h.device)
                     for _ in range(batch_size)]
         with torch.no_grad():
             scales = np.asarray(scales, dtype=np.float32)
@@ -135,10 +139,72 @@ class MaskRCNN(torch.nn.Module):
             rois = torch.tensor(rois, dtype=torch.float32, device=h.device)
             _, _, roi_masks = self.head(
                 h, rois, torch.tensor(roi_indices, device=h.device), pred_bbox=False)
+        if not to_host:
+            idx = torch.tensor(roi_indices, device=h.device)
+            return [roi_masks[idx == i] for i in range(batch_size)]
         roi_masks = roi_masks.cpu().numpy()
         return [roi_masks[roi_indices == i] for i in range(batch_size)]
 
-    def predict_prepared(self, x, scales, sizes):
+    # ------------------------------------------------------------------ image I/O on device
+    def prepare(self, imgs):
+        """models/mask_rcnn.py:152-176 + concat_examples(padding=0): a list of CHW RGB images
+        (uint8 or float) -> zero-padded device batch x (N,3,H,W) channels-last, original
+        sizes and scales.  The bilinear resize (cv2 INTER_LINEAR rule) and the mean
+        subtraction run in one HIP kernel per image."""
+        dev = next(self.parameters()).device
+        sizes, scales, outs = [], [], []
+        for img in imgs:
+            _, H, W = img.shape
+            scale = 1.
+            if self.min_size:
+                scale = self.min_size / min(H, W)
+            if self.max_size and scale * max(H, W) > self.max_size:
+                scale = self.max_size / max(H, W)
+            sizes.append((H, W))
+            scales.append(scale)
+            outs.append((int(np.round(H * scale)), int(np.round(W * scale))))
+        N = len(imgs)
+        Hm, Wm = max(o[0] for o in outs), max(o[1] for o in outs)
+        batch = torch.zeros((N, Hm, Wm, 3), dtype=torch.float32, device=dev)
+        mean = (_lib.c_f32 * 3)(*[float(v) for v in np.asarray(self.mean).ravel()])
+        for n, img in enumerate(imgs):
+            src = torch.as_tensor(np.ascontiguousarray(img, dtype=np.float32)).to(dev)
+            _lib.call('mrcnn_prepare_image', _lib.ptr(src), 3, sizes[n][0], sizes[n][1],
+                      float(scales[n]), mean, _lib.ptr(batch), Hm, Wm, outs[n][0], outs[n][1], n,
+                      _lib.stream_ptr())
+        return batch.permute(0, 3, 1, 2), sizes, scales
+
+    def _to_masks(self, bboxes, labels, scores, roi_masks, sizes):
+        """sigmoid + segm_results (models/mask_rcnn.py:63-107,292-305) on the device:
+        per-image (D, im_h, im_w) bool arrays."""
+        masks = []
+        for bbox, label, roi_mask, size in zip(bboxes, labels, roi_masks, sizes):
+            D = len(bbox)
+            if D == 0:
+                masks.append(np.zeros((0, size[0], size[1]), dtype=bool))
+                continue
+            from ..functions._layout import nhwc
+            logits = nhwc(roi_mask)
+            dev = logits.device
+            out = torch.empty((D, size[0], size[1]), dtype=torch.uint8, device=dev)
+            label_d = torch.tensor(label, dtype=torch.int32, device=dev)
+            bbox_d = torch.tensor(bbox, dtype=torch.float32, device=dev)
+            _lib.call('mrcnn_paste_masks', _lib.ptr(logits), _lib.ptr(label_d), _lib.ptr(bbox_d),
+                      D, logits.shape[2], logits.shape[1], int(size[0]), int(size[1]),
+                      _lib.ptr(out), _lib.stream_ptr())
+            masks.append(out.cpu().numpy().astype(bool))
+        return masks
+
+    def predict(self, imgs):
+        """Detect objects in a list of CHW RGB images (models/mask_rcnn.py:307-337):
+        returns (bboxes, masks, labels, scores), per-image lists as the reference."""
+        x, sizes, scales = self.prepare(imgs)
+        bboxes, roi_masks, labels, scores = self.predict_prepared(
+            x, scales, sizes, masks_to_host=False)
+        masks = self._to_masks(bboxes, labels, scores, roi_masks, sizes)
+        return bboxes, masks, labels, scores
+
+    def predict_prepared(self, x, scales, sizes, masks_to_host=True):
         """The device part of ``predict`` (:311-335) on an already prepared, zero-padded
         batch x (N,3,H,W) with per-image ``scales`` and original ``sizes`` (H,W).
 
@@ -165,7 +231,7 @@ class MaskRCNN(torch.nn.Module):
                 roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales)
             roi_indices = np.concatenate(
                 [np.full((len(b),), i, dtype=np.int32) for i, b in enumerate(bboxes)], axis=0)
-            roi_masks = self._to_roi_masks(h, bboxes, roi_indices, scales)
+            roi_masks = self._to_roi_masks(h, bboxes, roi_indices, scales, to_host=masks_to_host)
         finally:
             self.train(was_training)
         return bboxes, roi_masks, labels, scores

@@ -55,3 +55,92 @@ def finish(bbox, label, score, detections_per_im=100):
         keep = indices >= (len(indices) - detections_per_im)
         bbox, label, score = bbox[keep], label[keep], score[keep]
     return bbox, label, score
+
+
+# --------------------------------------------------------------------------------------
+# cv2-free restatement of the image I/O of MaskRCNN.predict (mask_rcnn.py:44-107,152-176).
+# OpenCV's resize(INTER_LINEAR) for float32 images: for every destination index d
+#   f = (float)((d + 0.5) * scale - 0.5); s = floor(f); f -= s;  clamp s to [0, n-1] with f = 0,
+# horizontal blend first, then vertical.  cv2 is not installable here: "parity unpinned".
+# --------------------------------------------------------------------------------------
+
+def _cv_axis(n_out, n_in, scale):
+    d = np.arange(n_out, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    t = (f - s.astype(np.float32)).astype(np.float32)
+    lo, hi = s < 0, s >= n_in - 1
+    s = np.clip(s, 0, n_in - 1)
+    t[lo | hi] = 0.
+    return s, np.minimum(s + 1, n_in - 1), t
+
+
+def cv_resize_linear(img, out_h, out_w, scale_y=None, scale_x=None):
+    """img (h, w) float32 -> (out_h, out_w); scale_* = source pixels per destination pixel
+    (default n_in / n_out, what cv2.resize(img, (w, h)) uses; cv2.resize(img, None, fx=s)
+    uses 1 / s)."""
+    img = np.asarray(img, np.float32)
+    h, w = img.shape
+    y0, y1, ty = _cv_axis(out_h, h, h / float(out_h) if scale_y is None else scale_y)
+    x0, x1, tx = _cv_axis(out_w, w, w / float(out_w) if scale_x is None else scale_x)
+    one = np.float32(1)
+    r0, r1 = img[y0], img[y1]
+    top = r0[:, x0] * (one - tx)[None, :] + r0[:, x1] * tx[None, :]
+    bot = r1[:, x0] * (one - tx)[None, :] + r1[:, x1] * tx[None, :]
+    return (top * (one - ty)[:, None] + bot * ty[:, None]).astype(np.float32)
+
+
+def prepare(img, mean, min_size, max_size):
+    """MaskRCNN.prepare for one CHW image (mask_rcnn.py:152-176) -> (prepared CHW f32, scale)."""
+    _, H, W = img.shape
+    scale = 1.
+    if min_size:
+        scale = min_size / min(H, W)
+    if max_size and scale * max(H, W) > max_size:
+        scale = max_size / max(H, W)
+    out_h, out_w = int(np.round(H * scale)), int(np.round(W * scale))   # cvRound(src * f)
+    out = np.stack([cv_resize_linear(img[c].astype(np.float32), out_h, out_w, 1. / scale, 1. / scale)
+                    for c in range(img.shape[0])])
+    return (out - np.asarray(mean, np.float32).reshape(-1, 1, 1)).astype(np.float32), scale
+
+
+def expand_boxes(boxes, scale):
+    """mask_rcnn.py:44-60 (float32 arithmetic on float32 boxes, float64 result array)."""
+    w_half = (boxes[:, 2] - boxes[:, 0]) * np.float32(.5)
+    h_half = (boxes[:, 3] - boxes[:, 1]) * np.float32(.5)
+    x_c = (boxes[:, 2] + boxes[:, 0]) * np.float32(.5)
+    y_c = (boxes[:, 3] + boxes[:, 1]) * np.float32(.5)
+    w_half = w_half * np.float32(scale)
+    h_half = h_half * np.float32(scale)
+    out = np.zeros(boxes.shape)
+    out[:, 0] = x_c - w_half
+    out[:, 2] = x_c + w_half
+    out[:, 1] = y_c - h_half
+    out[:, 3] = y_c + h_half
+    return out
+
+
+def segm_results(bbox, label, roi_mask_logits, im_h, im_w):
+    """mask_rcnn.py:63-107 with the sigmoid of _to_masks (:296) folded in.
+    bbox (D,4) yx f32, label (D,), roi_mask_logits (D, n_fg, M, M) -> (D, im_h, im_w) bool."""
+    if len(bbox) == 0:
+        return np.zeros((0, im_h, im_w), dtype=bool)
+    M = roi_mask_logits.shape[2]
+    prob = (1. / (1. + np.exp(-roi_mask_logits.astype(np.float64)))).astype(np.float32)
+    ref_boxes = expand_boxes(bbox[:, [1, 0, 3, 2]].astype(np.float32), (M + 2.0) / M)
+    ref_boxes = ref_boxes.astype(np.int32)
+    padded = np.zeros((M + 2, M + 2), dtype=np.float32)
+    out = []
+    for i in range(len(ref_boxes)):
+        padded[1:-1, 1:-1] = prob[i, label[i]]
+        rb = ref_boxes[i]
+        w = max(rb[2] - rb[0] + 1, 1)
+        h = max(rb[3] - rb[1] + 1, 1)
+        mask = (cv_resize_linear(padded, h, w) > 0.5).astype(np.uint8)
+        im_mask = np.zeros((im_h, im_w), dtype=np.uint8)
+        x_0, x_1 = max(rb[0], 0), min(rb[2] + 1, im_w)
+        y_0, y_1 = max(rb[1], 0), min(rb[3] + 1, im_h)
+        if x_1 > x_0 and y_1 > y_0:
+            im_mask[y_0:y_1, x_0:x_1] = mask[(y_0 - rb[1]):(y_1 - rb[1]), (x_0 - rb[0]):(x_1 - rb[0])]
+        out.append(im_mask.astype(bool))
+    return np.asarray(out)

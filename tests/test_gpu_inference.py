@@ -61,3 +61,66 @@ def test_decode_cls_boxes_bit_exact(dev):
               1.6, mean, std, 600., 900., _lib.stream_ptr())
     ref = np_infer.decode_cls_boxes(roi, loc, n_class, 1.6, (600, 900)).reshape(R, n_class, 4)
     assert (out.cpu().numpy() != ref).mean() < 1e-6
+
+
+def test_prepare_matches_oracle(dev):
+    """MaskRCNN.prepare on the device (resize + mean + zero-padded batch) vs the oracle."""
+    torch.manual_seed(0)
+    rng = np.random.RandomState(2)
+    model = cmr.models.MaskRCNNResNet(50, n_fg_class=80, min_size=160, max_size=240,
+                                      anchor_scales=(2, 4, 8, 16, 32), roi_size=14).to(dev)
+    imgs = [rng.randint(0, 256, (3, 97, 131)).astype(np.uint8),
+            rng.uniform(0, 255, (3, 120, 90)).astype(np.float32),
+            rng.randint(0, 256, (3, 60, 200)).astype(np.uint8)]      # max_size rule kicks in
+    x, sizes, scales = model.prepare(imgs)
+    x = x.cpu().numpy()
+    assert sizes == [(97, 131), (120, 90), (60, 200)]
+    for n, img in enumerate(imgs):
+        ref, scale = np_infer.prepare(img, model.mean.ravel(), 160, 240)
+        assert abs(scale - scales[n]) < 1e-12
+        h, w = ref.shape[1:]
+        np.testing.assert_allclose(x[n, :, :h, :w], ref, rtol=0, atol=2e-4)
+        assert (x[n, :, h:, :] == 0).all() and (x[n, :, :, w:] == 0).all()   # padding=0
+
+
+def test_paste_masks_matches_oracle(dev):
+    """segm_results on the device vs the oracle: the pasted image-size masks are an integer
+    (bool) result."""
+    rng = np.random.RandomState(3)
+    D, n_fg, M, im_h, im_w = 40, 80, 14, 150, 210
+    logits = (rng.standard_normal((D, n_fg, M, M)) * 3).astype(np.float32)
+    label = rng.randint(0, n_fg, D).astype(np.int32)
+    y0 = rng.uniform(-10, im_h - 5, D); x0 = rng.uniform(-10, im_w - 5, D)
+    bbox = np.stack([y0, x0, y0 + rng.uniform(1, 120, D), x0 + rng.uniform(1, 150, D)], 1).astype(np.float32)
+    bbox[0] = [3.2, 4.7, 3.9, 5.1]                      # sub-pixel box
+    bbox[1] = [-20, -30, im_h + 15, im_w + 40]          # larger than the image
+    model = cmr.models.MaskRCNN(None, None, None, mean=None)
+    masks = model._to_masks([bbox], [label], None, [torch.tensor(logits, device=dev)], [(im_h, im_w)])
+    ref = np_infer.segm_results(bbox, label, logits, im_h, im_w)
+    assert masks[0].dtype == bool and masks[0].shape == ref.shape
+    assert (masks[0] != ref).mean() < 1e-6
+    assert ref.any()
+
+
+def test_predict_end_to_end_api(dev):
+    """model.predict(list of CHW images) -> (bboxes, masks, labels, scores) as the reference."""
+    torch.manual_seed(0)
+    rng = np.random.RandomState(4)
+    model = cmr.models.MaskRCNNResNet(50, n_fg_class=80, min_size=160, max_size=240,
+                                      anchor_scales=(2, 4, 8, 16, 32), roi_size=14,
+                                      proposal_creator_params=dict(min_size=0, n_test_pre_nms=300,
+                                                                   n_test_post_nms=50)).to(dev)
+    with torch.no_grad():
+        model.extractor.bn1.W.fill_(1. / 64.)
+        model.head.cls_loc_score.W[4 * 81:5 * 81] *= 300.
+    imgs = [rng.randint(0, 256, (3, 100, 140)).astype(np.uint8),
+            rng.randint(0, 256, (3, 120, 90)).astype(np.uint8)]
+    bboxes, masks, labels, scores = model.predict(imgs)
+    assert len(bboxes) == len(masks) == len(labels) == len(scores) == 2
+    for img, b, m, l, s in zip(imgs, bboxes, masks, labels, scores):
+        assert b.dtype == np.float32 and l.dtype == np.int32 and s.dtype == np.float32
+        assert m.dtype == bool and m.shape == (len(b),) + img.shape[1:]
+        assert len(b) == len(l) == len(s) <= 100
+        if len(b):
+            assert b[:, 0::2].min() >= 0 and b[:, 0::2].max() <= img.shape[1]
+            assert (s > 0.05).all() and l.min() >= 0 and l.max() < 80
