@@ -43,6 +43,15 @@ constexpr bool SETPRIO = MRCNN_GEMM_SETPRIO != 0;
 #define MRCNN_GEMM_PINGPONG 0   // measured slower than two free-running workgroups per CU
 #endif
 constexpr bool USE_PINGPONG = MRCNN_GEMM_PINGPONG != 0;
+// The plain forward kernel (no mask staging) fits 168 registers, so it runs with ONE LDS stage
+// (37 KB) and three workgroups per CU: a wave spends ~40 % of a K slice issuing MFMAs and
+// ~60 % staging (measured with s_memtime), so three interleaved waves per SIMD keep the pipe
+// fuller than two (res5 3x3: 129 vs 122 TFLOP/s).  DGRAD / WGRAD need more registers (they
+// would spill at 168) and keep two stages / two workgroups per CU.
+#ifndef MRCNN_GEMM_SINGLEBUF
+#define MRCNN_GEMM_SINGLEBUF 1
+#endif
+constexpr bool single_buffered(int tm, int mode) { return MRCNN_GEMM_SINGLEBUF != 0 && tm == 2 && mode == 0; }
 constexpr int KPAD = 4;  // K-contiguous LDS rows are 36 floats (conflict-free b128)
 
 // FWDM = forward-form gather whose A operand carries the fused epilogue-backward (mask /
@@ -82,6 +91,10 @@ struct GemmParams {
     const float *res_g, *res_y;
     unsigned a_bytes, b_bytes, c_bytes;  // buffer extents (bytes) of A (and mask_y), B, C
 };
+
+#ifdef MRCNN_GEMM_TRACE
+__device__ unsigned long long g_trace[64 * 4 * 64 * 5];
+#endif
 
 template <int TM, int TN, int MODE>
 struct Cfg {
@@ -147,15 +160,16 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
 // one wave per SIMD cannot keep the fp32 MFMA pipe as full as two interleaved waves do.  Kept
 // as a compile-time experiment (-DMRCNN_GEMM_PINGPONG=1), off by default.
 template <int TM, int TN, int MODE, bool PP>
-__global__ void __launch_bounds__(PP ? 512 : 256, MRCNN_GEMM_MINWAVES)
+__global__ void __launch_bounds__(PP ? 512 : 256, single_buffered(TM, MODE) ? 3 : MRCNN_GEMM_MINWAVES)
 conv_gemm_kernel(const GemmParams p)
 {
+    constexpr bool SINGLEBUF = single_buffered(TM, MODE) && !PP;
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
     constexpr int AV = C_::A_V4, BV = C_::B_V4;
     constexpr bool HAS_MASK = (MODE != FWD);
     constexpr bool FWDLIKE = is_fwd(MODE);
-    __shared__ __attribute__((aligned(16))) float smem_all[PP ? 2 : 1][2][C_::A_FLOATS + C_::B_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem_all[PP ? 2 : 1][SINGLEBUF ? 1 : 2][C_::A_FLOATS + C_::B_FLOATS];
 
     const int grp = PP ? (int)(threadIdx.x >> 8) : 0;   // ping-pong group (wave-uniform)
     float (*smem)[C_::A_FLOATS + C_::B_FLOATS] = smem_all[grp];
@@ -240,23 +254,56 @@ conv_gemm_kernel(const GemmParams p)
     if (MODE == WGRAD && use_scale && m0 + wa_c4 * 4 < p.M)
         rscale = *reinterpret_cast<const float4 *>(p.in_scale + m0 + wa_c4 * 4);
 
-    // issue the global loads of slice kt (nothing here consumes a loaded value)
+    // Loop-invariant parts of every load address (element offsets; an invalid row carries the
+    // sentinel 0x20000000 so that 4 * offset lands beyond num_records and reads as zero).
+    constexpr unsigned kBad = 0x20000000u;
+    unsigned a_base[AV], b_base[BV];
+    if (MODE != WGRAD) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i)
+            a_base[i] = (unsigned)(((a_n[i] * p.sh + a_y[i]) * p.sw + a_x[i]) * p.lda + kc_c4 * 4);
+        if (FWDLIKE) {
+#pragma unroll
+            for (int i = 0; i < BV; ++i) {
+                const int n = n0 + kc_row + KC_RPP * i;
+                b_base[i] = n < p.N ? (unsigned)(n * p.ldb + kc_c4 * 4) : kBad;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BV; ++i) {
+                const int n = n0 + wb_c4 * 4;
+                b_base[i] = n < p.N ? (unsigned)((wb_k + B_RPP * i) * p.ldb + n) : kBad;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int k = m0 + wa_c4 * 4;
+            a_base[i] = k < p.M ? (unsigned)((wa_k + A_RPP * i) * p.ldg + k) : kBad;
+        }
+    }
+    const int RS = p.R * p.S;
+
+    // issue the global loads of slice kt (nothing here consumes a loaded value).
+    // FWD/DGRAD K order: channel chunk outer, filter tap (r,s) inner — consecutive slices re-read
+    // the same 32-channel slab of neighbouring pixels, which stays in the CU's L1.
     auto load_slice = [&](int kt) {
         if (FWDLIKE || MODE == DGRAD) {
-            const int rs = kt / cprs;
-            const int c0 = (kt - rs * cprs) * BK;
+            const int chunk = kt / RS;
+            const int rs = kt - chunk * RS;
+            const int c0 = chunk * BK;
             const int r = rs / p.S, s = rs - r * p.S;
             const int cc = c0 + kc_c4 * 4;
             const bool c_ok = p.stem || cc < p.Kc;
+            // wave-uniform part of the A address for this slice
+            const int tap = (FWDLIKE ? (r * p.sw + s) : -(r * p.sw + s)) * p.lda + c0;
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
                 int iy, ix;
                 if (FWDLIKE) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? (cc >> 2) : 0); }
                 else { iy = a_y[i] - r; ix = a_x[i] - s; }
                 const bool ok = c_ok && (unsigned)iy < (unsigned)p.sh && (unsigned)ix < (unsigned)p.sw;
-                const unsigned off =
-                    ok ? 4u * (unsigned)(((a_n[i] * p.sh + iy) * p.sw + ix) * p.lda + (p.stem ? 0 : cc))
-                       : kOOB;
+                const unsigned off = ok ? 4u * (a_base[i] + (unsigned)tap) : kOOB;
                 ra[i] = bload4(rA, off);
                 if (HAS_MASK && use_mask) rm[i] = bload4(rMask, off);
             }
@@ -264,29 +311,25 @@ conv_gemm_kernel(const GemmParams p)
                 rscale = cc < p.Kc ? *reinterpret_cast<const float4 *>(p.in_scale + cc)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
             if (FWDLIKE) {
+                const unsigned wofs = (unsigned)(rs * p.Kc + c0);
 #pragma unroll
-                for (int i = 0; i < BV; ++i) {
-                    const int n = n0 + kc_row + KC_RPP * i;
-                    const bool ok = n < p.N && cc < p.Kc;
-                    rb[i] = bload4(rB, ok ? 4u * (unsigned)(n * p.ldb + rs * p.Kc + cc) : kOOB);
-                }
+                for (int i = 0; i < BV; ++i)
+                    rb[i] = bload4(rB, cc < p.Kc ? 4u * (b_base[i] + wofs) : kOOB);
             } else {
+                const unsigned wofs = (unsigned)(c0 * p.ldb + rs * p.cin);
 #pragma unroll
                 for (int i = 0; i < BV; ++i) {
                     const int k = c0 + wb_k + B_RPP * i;
-                    const int n = n0 + wb_c4 * 4;
-                    const bool ok = k < p.Kc && n < p.N;
-                    rb[i] = bload4(rB, ok ? 4u * (unsigned)(k * p.ldb + rs * p.cin + n) : kOOB);
+                    rb[i] = bload4(rB, k < p.Kc ? 4u * (b_base[i] + wofs) : kOOB);
                 }
             }
         } else {
             const int kb = k_begin + kt * BK;
+            const unsigned gofs = (unsigned)(kb * p.ldg);
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
                 const int m = kb + wa_k + A_RPP * i;
-                const int k = m0 + wa_c4 * 4;
-                const bool ok = m < k_end && k < p.M;
-                const unsigned off = ok ? 4u * (unsigned)(m * p.ldg + k) : kOOB;
+                const unsigned off = m < k_end ? 4u * (a_base[i] + gofs) : kOOB;
                 ra[i] = bload4(rA, off);
                 if (use_mask) rm[i] = bload4(rMask, off);
             }
@@ -437,15 +480,49 @@ conv_gemm_kernel(const GemmParams p)
             }
             __syncthreads();
         }
+    } else if (SINGLEBUF) {
+        // one LDS stage (37 KB -> three workgroups per CU, three waves per SIMD): a wave spends
+        // ~40 % of a slice issuing MFMAs and ~60 % staging, so three interleaved waves are
+        // needed to keep the pipe full; two barriers per slice instead of one.
+        for (int kt = 0; kt < nslices; ++kt) {
+            if (kt > 0) {
+                __syncthreads();          // every wave is done reading the stage
+                store_slice(0);
+            }
+            __syncthreads();
+            if (kt + 1 < nslices) load_slice(kt + 1);
+            compute(0);
+        }
     } else {
         __syncthreads();
+#ifdef MRCNN_GEMM_TRACE
+        // developer instrumentation: per-phase s_memtime stamps of one wave per block
+        unsigned long long *tr = g_trace + ((size_t)blockIdx.x * 4 + wave) * 64 * 5;
+        const bool tr_on = blockIdx.x < 64 && lane == 0 && blockIdx.y == 0;
+#define TRACE_STAMP(slot)                                                        \
+    if (tr_on && kt >= 8 && kt < 72) {                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+        tr[(kt - 8) * 5 + slot] = __builtin_amdgcn_s_memtime();                  \
+    }
+#else
+#define TRACE_STAMP(slot)
+#endif
         for (int kt = 0; kt < nslices; ++kt) {
             const bool more = kt + 1 < nslices;
+            TRACE_STAMP(0)
             if (more) load_slice(kt + 1);
+            TRACE_STAMP(1)
             compute(kt & 1);
+            TRACE_STAMP(2)
+#ifdef MRCNN_GEMM_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            TRACE_STAMP(3)
             if (more) store_slice((kt + 1) & 1);
             __syncthreads();
+            TRACE_STAMP(4)
         }
+#undef TRACE_STAMP
     }
 
     // ---------------- epilogue ------------------------------------------------------
@@ -594,9 +671,17 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
     if (!big_ok || T < 384) {
         launch_tiles<1, 1, MODE>(p, 0, p.M, splits, s);
     } else {
-        const int64_t full = T / kSlotsBig, rem = T - full * kSlotsBig;
-        int64_t main_tiles_m = tm;
-        if (full >= 1 && rem > 0 && rem * 10 < kSlotsBig * 6) main_tiles_m = (full * kSlotsBig) / tn;
+        // whole "rounds" of k workgroups per CU (k = 3, 2, 1): pick the round size that leaves
+        // the smallest leftover, run the leftover rows as 64x64 tiles
+        const int64_t max_per_cu = single_buffered(2, MODE) ? 3 : 2;
+        int64_t main_tiles_m = tm, best_rem = T;
+        for (int64_t k = max_per_cu; k >= 1; --k) {
+            const int64_t slots = 256 * k, full = T / slots, rem = T - full * slots;
+            if (full >= 1 && rem < best_rem) {
+                best_rem = rem;
+                main_tiles_m = rem > 0 && rem < 154 ? (full * slots) / tn : tm;
+            }
+        }
         const int rows_main = (int)std::min<int64_t>(p.M, main_tiles_m * 128);
         launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
         if (rows_main < p.M) launch_tiles<1, 1, MODE>(p, rows_main, p.M, splits, s);
@@ -654,6 +739,14 @@ int wgrad_splits(int64_t tiles, int64_t pixels, int64_t slots)
 }
 
 }  // namespace
+
+#ifdef MRCNN_GEMM_TRACE
+extern "C" int mrcnn_gemm_trace_read(unsigned long long *host, int n)
+{
+    MRCNN_HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n));
+    return 0;
+}
+#endif
 
 extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                                 const float *bias, const float *scale, const float *shift,
