@@ -43,22 +43,31 @@ constexpr bool SETPRIO = MRCNN_GEMM_SETPRIO != 0;
 #define MRCNN_GEMM_PINGPONG 0   // measured slower than two free-running workgroups per CU
 #endif
 constexpr bool USE_PINGPONG = MRCNN_GEMM_PINGPONG != 0;
-// The plain forward kernel (no mask staging) fits 168 registers, so it runs with ONE LDS stage
+// The forward-form kernel without mask staging fits 168 registers, so it runs with ONE LDS stage
 // (37 KB) and three workgroups per CU: a wave spends ~40 % of a K slice issuing MFMAs and
 // ~60 % staging (measured with s_memtime), so three interleaved waves per SIMD keep the pipe
-// fuller than two (res5 3x3: 129 vs 122 TFLOP/s).  DGRAD / WGRAD need more registers (they
-// would spill at 168) and keep two stages / two workgroups per CU.
+// fuller than two (res5 3x3: 129 vs 122 TFLOP/s).  The variants that stage a mask (16 more
+// registers) and the K-strided DGRAD gather would spill at 168 and keep two stages / two
+// workgroups per CU.
 #ifndef MRCNN_GEMM_SINGLEBUF
 #define MRCNN_GEMM_SINGLEBUF 1
 #endif
-constexpr bool single_buffered(int tm, int mode) { return MRCNN_GEMM_SINGLEBUF != 0 && tm == 2 && mode == 0; }
+#ifndef MRCNN_GEMM_SINGLEBUF_WGRAD
+#define MRCNN_GEMM_SINGLEBUF_WGRAD 1
+#endif
+constexpr bool single_buffered(int tm, int mode, bool masked)
+{
+    return MRCNN_GEMM_SINGLEBUF != 0 && tm == 2 && !masked &&
+           (mode == 0 || (mode == 2 && MRCNN_GEMM_SINGLEBUF_WGRAD != 0));
+}
 constexpr int KPAD = 4;  // K-contiguous LDS rows are 36 floats (conflict-free b128)
 
-// FWDM = forward-form gather whose A operand carries the fused epilogue-backward (mask /
-// scale) and whose epilogue may add the shortcut gradient: the stride-1 dgrad expressed as a
-// forward convolution of gy with the flipped, transposed filter (both operands K-contiguous).
-enum Mode { FWD = 0, DGRAD = 1, WGRAD = 2, FWDM = 3 };
-constexpr bool is_fwd(int m) { return m == FWD || m == FWDM; }
+// The stride-1 dgrad is also run in FWD mode: a forward convolution of gy with the flipped,
+// transposed filter (both operands K-contiguous).  MASKED (template flag of the kernel) adds
+// the fused epilogue-backward of the producing conv to the A staging: g = gy * (mask_y > 0) *
+// in_scale[k].
+enum Mode { FWD = 0, DGRAD = 1, WGRAD = 2 };
+constexpr bool is_fwd(int m) { return m == FWD; }
 enum OutMode { OUT_PLAIN = 0, OUT_STRIDED = 1, OUT_DECONV = 2 };
 
 struct GemmParams {
@@ -87,8 +96,14 @@ struct GemmParams {
     // (DGRAD A operand / WGRAD A' operand):  g = gy * (mask_y > 0) * in_scale[k]
     const float *mask_y;   // output of the ReLU that followed the conv (same shape as gy) or NULL
     const float *in_scale; // AffineChannel2D scale of that conv (K_out) or NULL
-    // DGRAD epilogue: gx += res_g * (res_y > 0)  (identity-shortcut gradient of a bottleneck)
-    const float *res_g, *res_y;
+    // backward-data epilogue: gx = (acc * scale[c] + res_g * (res_y > 0)) * (out_mask_y > 0)
+    //   res_g / res_y : identity-shortcut gradient of a bottleneck (res_y NULL: res_g is added as is)
+    //   out_mask_y    : output of the ReLU that produced this conv's INPUT, i.e. the epilogue-
+    //                   backward of the NEXT conv down the chain applied where its incoming
+    //                   gradient is produced (then that conv needs no mask staging at all)
+    // WGRAD epilogue: gw[k, :] *= scale[k]
+    const float *res_g, *res_y, *out_mask_y;
+    int prof_kind;       // host only: profiler bucket of the 128x128 launch
     unsigned a_bytes, b_bytes, c_bytes;  // buffer extents (bytes) of A (and mask_y), B, C
 };
 
@@ -159,15 +174,15 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
 // Measured on MI355X (round 1): the strict antiphase is SLOWER (res5 3x3 fwd 110 vs 122 TF/s):
 // one wave per SIMD cannot keep the fp32 MFMA pipe as full as two interleaved waves do.  Kept
 // as a compile-time experiment (-DMRCNN_GEMM_PINGPONG=1), off by default.
-template <int TM, int TN, int MODE, bool PP>
-__global__ void __launch_bounds__(PP ? 512 : 256, single_buffered(TM, MODE) ? 3 : MRCNN_GEMM_MINWAVES)
+template <int TM, int TN, int MODE, bool MASKED, bool PP>
+__global__ void __launch_bounds__(PP ? 512 : 256, single_buffered(TM, MODE, MASKED) ? 3 : MRCNN_GEMM_MINWAVES)
 conv_gemm_kernel(const GemmParams p)
 {
-    constexpr bool SINGLEBUF = single_buffered(TM, MODE) && !PP;
+    constexpr bool SINGLEBUF = single_buffered(TM, MODE, MASKED) && !PP;
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
     constexpr int AV = C_::A_V4, BV = C_::B_V4;
-    constexpr bool HAS_MASK = (MODE != FWD);
+    constexpr bool HAS_MASK = MASKED;
     constexpr bool FWDLIKE = is_fwd(MODE);
     __shared__ __attribute__((aligned(16))) float smem_all[PP ? 2 : 1][SINGLEBUF ? 1 : 2][C_::A_FLOATS + C_::B_FLOATS];
 
@@ -534,10 +549,13 @@ conv_gemm_kernel(const GemmParams p)
     const __amdgpu_buffer_rsrc_t rRes = make_rsrc(p.residual, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rResG = make_rsrc(p.res_g, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rResY = make_rsrc(p.res_y, p.c_bytes);
+    const __amdgpu_buffer_rsrc_t rOutM = make_rsrc(p.out_mask_y, p.c_bytes);
     const bool f_bias = (p.flags & MRCNN_EPI_BIAS) != 0, f_aff = (p.flags & MRCNN_EPI_AFFINE) != 0;
     const bool f_res = (p.flags & MRCNN_EPI_RESIDUAL) != 0, f_relu = (p.flags & MRCNN_EPI_RELU) != 0;
     const bool f_acc = (p.flags & MRCNN_EPI_ACCUM) != 0;
-    const bool f_resg = (MODE == DGRAD || MODE == FWDM) && p.res_g != nullptr;
+    const bool f_resg = MODE != WGRAD && p.res_g != nullptr;
+    const bool f_resy = f_resg && p.res_y != nullptr;
+    const bool f_outm = MODE != WGRAD && p.out_mask_y != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (32 * TN) + j * 32 + li;
@@ -546,7 +564,7 @@ conv_gemm_kernel(const GemmParams p)
         float bias = 0.f, scale = 1.f, shift = 0.f;
         if (MODE != WGRAD) {
             if (f_bias) bias = p.bias[p.out_mode == OUT_DECONV ? colc % p.ko : colc];
-            if (f_aff) { scale = p.scale[colc]; shift = p.shift[colc]; }
+            if (f_aff) { scale = p.scale[colc]; shift = p.shift ? p.shift[colc] : 0.f; }
         }
         int col_off = colc;
         if (MODE == DGRAD && p.out_mode == OUT_DECONV) {
@@ -577,7 +595,7 @@ conv_gemm_kernel(const GemmParams p)
                     }
                     off[q] = (col_ok && row < p.M) ? 4u * (unsigned)o : kOOB;
                 }
-                float aux0[8], aux1[8], aux2[8];
+                float aux0[8], aux1[8], aux2[8], aux3[8];
                 if (MODE != WGRAD) {
                     if (f_res) {
 #pragma unroll
@@ -589,7 +607,24 @@ conv_gemm_kernel(const GemmParams p)
                     }
                     if (f_resg) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) { aux0[q] = bload1(rResG, off[q]); aux2[q] = bload1(rResY, off[q]); }
+                        for (int q = 0; q < 8; ++q) aux0[q] = bload1(rResG, off[q]);
+                    }
+                    if (f_resy) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) aux2[q] = bload1(rResY, off[q]);
+                    }
+                    if (f_outm) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) aux3[q] = bload1(rOutM, off[q]);
+                    }
+                }
+                float row_scale[8];
+                if (MODE == WGRAD && p.scale) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = g * 8 + q;
+                        const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                        row_scale[q] = row < p.M ? p.scale[row] : 0.f;
                     }
                 }
 #pragma unroll
@@ -600,8 +635,12 @@ conv_gemm_kernel(const GemmParams p)
                         if (f_aff) v = v * scale + shift;
                         if (f_res) v += aux0[q];
                         if (f_acc) v += aux1[q];
-                        if (f_resg) v += aux2[q] > 0.f ? aux0[q] : 0.f;
+                        if (f_resy) v += aux2[q] > 0.f ? aux0[q] : 0.f;
+                        else if (f_resg) v += aux0[q];
                         if (f_relu) v = fmaxf(v, 0.f);
+                        if (f_outm) v = aux3[q] > 0.f ? v : 0.f;
+                    } else if (p.scale) {
+                        v *= row_scale[q];
                     }
                     bstore1(rC, off[q], v);
                 }
@@ -628,16 +667,25 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, i
 // Workgroups resident at once: 128x128 tiles run 2 per CU (73 KB LDS), 64x64 tiles 4 per CU.
 constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
 
+template <int TM, int TN, int MODE, bool MASKED>
+void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t s)
+{
+    if constexpr (TM == 2 && USE_PINGPONG) {
+        hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
+                           dim3((unsigned)mrcnn::ceil_div(tiles, 2), splits), dim3(512), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false>),
+                           dim3((unsigned)tiles, splits), dim3(256), 0, s, p);
+    }
+}
+
+inline bool is_masked(const GemmParams &p) { return p.mask_y != nullptr || p.in_scale != nullptr; }
+
 template <int TM, int TN, int MODE>
 void launch_kernel(const GemmParams &p, int64_t tiles, int splits, hipStream_t s)
 {
-    if constexpr (TM == 2 && USE_PINGPONG) {
-        hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, true>),
-                           dim3((unsigned)mrcnn::ceil_div(tiles, 2), splits), dim3(512), 0, s, p);
-    } else {
-        hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, false>), dim3((unsigned)tiles, splits),
-                           dim3(256), 0, s, p);
-    }
+    if (is_masked(p)) launch_kernel_m<TM, TN, MODE, true>(p, tiles, splits, s);
+    else launch_kernel_m<TM, TN, MODE, false>(p, tiles, splits, s);
 }
 
 template <int TM, int TN, int MODE>
@@ -652,9 +700,7 @@ void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
     const double kdepth = (double)p.R * p.S * (p.stem ? 21.0 : (double)p.Kc);
     const double flops = 2.0 * rows * p.N * kdepth;
     const double bytes = 4.0 * ((double)rows * p.N + (double)rows * p.Kc + (double)p.N * kdepth);
-    mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
-                              (TM == 2 ? 0 : 1),
-                          flops, bytes, s);
+    mrcnn::ProfScope prof(p.prof_kind + (TM == 2 ? 0 : 1), flops, bytes, s);
     launch_kernel<TM, TN, MODE>(p, blocks, splits, s);
 }
 
@@ -673,7 +719,7 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
     } else {
         // whole "rounds" of k workgroups per CU (k = 3, 2, 1): pick the round size that leaves
         // the smallest leftover, run the leftover rows as 64x64 tiles
-        const int64_t max_per_cu = single_buffered(2, MODE) ? 3 : 2;
+        const int64_t max_per_cu = single_buffered(2, MODE, is_masked(p)) ? 3 : 2;
         int64_t main_tiles_m = tm, best_rem = T;
         for (int64_t k = max_per_cu; k >= 1; --k) {
             const int64_t slots = 256 * k, full = T / slots, rem = T - full * slots;
@@ -765,7 +811,7 @@ extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const 
     p.gp = d->P; p.gq = d->Q; p.sh = d->H; p.sw = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
     p.lda = d->C; p.ldb = d->R * d->S * d->C; p.ldc = d->K;
-    p.flags = epi_flags; p.out_mode = OUT_PLAIN;
+    p.flags = epi_flags; p.out_mode = OUT_PLAIN; p.prof_kind = mrcnn::PROF_CONV_FWD_128;
     if (int rc = set_extents(p, (int64_t)d->N * d->H * d->W * d->C, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->P * d->Q * d->K))
         return rc;
@@ -789,7 +835,7 @@ extern "C" int mrcnn_conv_stem_fwd(const float *x4, const float *w784, const flo
     p.gp = P; p.gq = Q; p.sh = H; p.sw = W;
     p.R = 7; p.S = 1; p.stride = 2; p.pad = 3;
     p.lda = 4; p.ldb = 7 * 32; p.ldc = K;
-    p.flags = epi_flags; p.out_mode = OUT_PLAIN; p.stem = 1;
+    p.flags = epi_flags; p.out_mode = OUT_PLAIN; p.stem = 1; p.prof_kind = mrcnn::PROF_CONV_FWD_128;
     if (int rc = set_extents(p, (int64_t)N * H * W * 4, (int64_t)K * 7 * 32, (int64_t)N * P * Q * K))
         return rc;
     return launch<FWD>(p, 1, mrcnn::as_stream(stream));
@@ -798,23 +844,26 @@ extern "C" int mrcnn_conv_stem_fwd(const float *x4, const float *w784, const flo
 extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, const float *w,
                                      float *gx, int epi_flags, const float *mask_y,
                                      const float *in_scale, const float *res_g,
-                                     const float *res_y, void *stream);
+                                     const float *res_y, const float *out_mask_y,
+                                     const float *out_scale, void *stream);
 
 extern "C" int mrcnn_conv2d_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w,
                                   float *gx, int epi_flags, void *stream)
 {
     return mrcnn_conv2d_dgrad_ex(d, gy, w, gx, epi_flags, nullptr, nullptr, nullptr, nullptr,
-                                 stream);
+                                 nullptr, nullptr, stream);
 }
 
 extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, const float *w,
                                      float *gx, int epi_flags, const float *mask_y,
                                      const float *in_scale, const float *res_g,
-                                     const float *res_y, void *stream)
+                                     const float *res_y, const float *out_mask_y,
+                                     const float *out_scale, void *stream)
 {
     if (int rc = check_desc(d)) return rc;
-    MRCNN_REQUIRE((res_g == nullptr) == (res_y == nullptr), "conv2d_dgrad: res_g/res_y go together");
-    MRCNN_REQUIRE(!res_g || d->stride == 1, "conv2d_dgrad: residual gradient needs stride 1");
+    MRCNN_REQUIRE(!res_y || res_g, "conv2d_dgrad: res_y without res_g");
+    MRCNN_REQUIRE((!res_g && !out_mask_y) || d->stride == 1,
+                  "conv2d_dgrad: residual gradient / output mask need stride 1");
     MRCNN_REQUIRE(gy && w && gx, "conv2d_dgrad: null pointer");
     MRCNN_REQUIRE(aligned16(gy) && aligned16(w), "conv2d_dgrad: gy/w must be 16-byte aligned");
     MRCNN_REQUIRE((epi_flags & ~MRCNN_EPI_ACCUM) == 0, "conv2d_dgrad: only MRCNN_EPI_ACCUM is valid");
@@ -822,10 +871,12 @@ extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, 
     GemmParams p = {};
     p.A = gy; p.B = w; p.C = gx;
     p.mask_y = mask_y; p.in_scale = in_scale; p.res_g = res_g; p.res_y = res_y;
+    p.out_mask_y = out_mask_y; p.scale = out_scale;
     p.N = d->C; p.Kc = d->K; p.cin = d->C;
     p.R = d->R; p.S = d->S; p.pad = d->pad;
     p.lda = d->K; p.ldb = d->R * d->S * d->C; p.ldc = d->C;
-    p.flags = epi_flags;
+    p.flags = epi_flags | (out_scale ? MRCNN_EPI_AFFINE : 0);
+    p.prof_kind = mrcnn::PROF_CONV_DGRAD_128;
     if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->H * d->W * d->C))
         return rc;
@@ -846,9 +897,10 @@ extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, 
 }
 
 namespace {
-// wT[c][R-1-r][S-1-s][k] = w[k][r][s][c]
+// wT[c][R-1-r][S-1-s][k] = w[k][r][s][c] * row_scale[k]
 __global__ void filter_flip_transpose_kernel(const float *__restrict__ w, float *__restrict__ wT,
-                                             int K, int RS, int C)
+                                             int K, int RS, int C,
+                                             const float *__restrict__ row_scale)
 {
     __shared__ float tile[32][33];
     const int rs = blockIdx.z;
@@ -856,7 +908,9 @@ __global__ void filter_flip_transpose_kernel(const float *__restrict__ w, float 
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int j = ty; j < 32; j += 8) {
         const int k = k0 + j, c = c0 + tx;
-        tile[j][tx] = (k < K && c < C) ? w[((int64_t)k * RS + rs) * C + c] : 0.f;
+        tile[j][tx] = (k < K && c < C)
+                          ? w[((int64_t)k * RS + rs) * C + c] * (row_scale ? row_scale[k] : 1.f)
+                          : 0.f;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
@@ -867,12 +921,12 @@ __global__ void filter_flip_transpose_kernel(const float *__restrict__ w, float 
 }  // namespace
 
 extern "C" int mrcnn_filter_flip_transpose(const float *w, float *wT, int K, int R, int S, int C,
-                                           void *stream)
+                                           const float *row_scale, void *stream)
 {
     MRCNN_REQUIRE(w && wT && K > 0 && R > 0 && S > 0 && C > 0, "filter_flip_transpose: bad args");
     hipLaunchKernelGGL(filter_flip_transpose_kernel,
                        dim3((C + 31) / 32, (K + 31) / 32, R * S), dim3(256), 0,
-                       mrcnn::as_stream(stream), w, wT, K, R * S, C);
+                       mrcnn::as_stream(stream), w, wT, K, R * S, C, row_scale);
     return mrcnn::check_launch("filter_flip_transpose");
 }
 
@@ -881,27 +935,30 @@ extern "C" int mrcnn_filter_flip_transpose(const float *w, float *wT, int K, int
 extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, const float *wT,
                                      float *gx, int epi_flags, const float *mask_y,
                                      const float *in_scale, const float *res_g,
-                                     const float *res_y, void *stream)
+                                     const float *res_y, const float *out_mask_y,
+                                     const float *out_scale, void *stream)
 {
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(d->stride == 1, "conv2d_dgrad_wt: stride must be 1");
     MRCNN_REQUIRE(gy && wT && gx, "conv2d_dgrad_wt: null pointer");
     MRCNN_REQUIRE(aligned16(gy) && aligned16(wT), "conv2d_dgrad_wt: gy/wT must be 16-byte aligned");
     MRCNN_REQUIRE((epi_flags & ~MRCNN_EPI_ACCUM) == 0, "conv2d_dgrad_wt: only MRCNN_EPI_ACCUM is valid");
-    MRCNN_REQUIRE((res_g == nullptr) == (res_y == nullptr), "conv2d_dgrad_wt: res_g/res_y go together");
+    MRCNN_REQUIRE(!res_y || res_g, "conv2d_dgrad_wt: res_y without res_g");
     GemmParams p = {};
     p.A = gy; p.B = wT; p.C = gx;
     p.mask_y = mask_y; p.in_scale = in_scale; p.res_g = res_g; p.res_y = res_y;
+    p.out_mask_y = out_mask_y; p.scale = out_scale;
+    p.prof_kind = mrcnn::PROF_CONV_DGRAD_128;
     p.M = d->N * d->H * d->W; p.N = d->C; p.Kc = d->K;
     p.gp = d->H; p.gq = d->W; p.sh = d->P; p.sw = d->Q;
     p.R = d->R; p.S = d->S; p.stride = 1; p.pad = d->R - 1 - d->pad;
     p.lda = d->K; p.ldb = d->R * d->S * d->K; p.ldc = d->C;
-    p.flags = epi_flags; p.out_mode = OUT_PLAIN;
+    p.flags = epi_flags | (out_scale ? MRCNN_EPI_AFFINE : 0); p.out_mode = OUT_PLAIN;
     MRCNN_REQUIRE(d->S - 1 - d->pad == p.pad, "conv2d_dgrad_wt: square filters / symmetric padding only");
     if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->H * d->W * d->C))
         return rc;
-    return launch<FWDM>(p, 1, mrcnn::as_stream(stream));
+    return launch<FWD>(p, 1, mrcnn::as_stream(stream));
 }
 
 extern "C" int64_t mrcnn_conv2d_wgrad_workspace_bytes(const mrcnn_conv_desc *d)
@@ -914,11 +971,11 @@ extern "C" int64_t mrcnn_conv2d_wgrad_workspace_bytes(const mrcnn_conv_desc *d)
 static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int Kout, int64_t pixels,
                       int N_, int H, int W, int C, int P, int Q, int R, int S, int stride, int pad,
                       void *ws, hipStream_t s, const float *mask_y = nullptr,
-                      const float *in_scale = nullptr)
+                      const float *in_scale = nullptr, const float *out_row_scale = nullptr)
 {
     GemmParams p = {};
     p.A = gy; p.B = x;
-    p.mask_y = mask_y; p.in_scale = in_scale;
+    p.mask_y = mask_y; p.in_scale = in_scale; p.scale = out_row_scale;
     p.M = Kout; p.N = R * S * C; p.Kc = (int)pixels;
     p.gp = P; p.gq = Q; p.sh = H; p.sw = W;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad;
@@ -930,9 +987,10 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     // the problem is at least one tile wide; otherwise 64x64 tiles.
     const int64_t small = mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
     const int64_t max_splits = std::min<int64_t>(64, std::max<int64_t>(1, pixels / (8 * BK)));
+    const int64_t slots_big = single_buffered(2, WGRAD, is_masked(p)) ? 768 : kSlotsBig;
     const bool use_big = p.N > 64 && p.M > 64 && big * max_splits * 2 >= kSlotsBig;
     const int64_t tiles = use_big ? big : small;
-    int splits = wgrad_splits(tiles, pixels, use_big ? kSlotsBig : kSlotsSmall);
+    int splits = wgrad_splits(tiles, pixels, use_big ? slots_big : kSlotsSmall);
     if (!ws) splits = 1;
     p.split_len = (int)(mrcnn::ceil_div(mrcnn::ceil_div(pixels, splits), BK) * BK);
     splits = (int)mrcnn::ceil_div(pixels, p.split_len);
@@ -957,7 +1015,8 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
 
 extern "C" int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float *gy,
                                      float *gw, void *ws, const float *mask_y,
-                                     const float *in_scale, void *stream)
+                                     const float *in_scale, const float *out_row_scale,
+                                     void *stream)
 {
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(x && gy && gw, "conv2d_wgrad: null pointer");
@@ -965,13 +1024,13 @@ extern "C" int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, c
                   "conv2d_wgrad: pointers must be 16-byte aligned");
     return wgrad_impl(gy, d->K, x, gw, d->K, (int64_t)d->N * d->P * d->Q, d->N, d->H, d->W, d->C,
                       d->P, d->Q, d->R, d->S, d->stride, d->pad, ws, mrcnn::as_stream(stream),
-                      mask_y, in_scale);
+                      mask_y, in_scale, out_row_scale);
 }
 
 extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc *d, const float *x, const float *gy,
                                   float *gw, void *ws, void *stream)
 {
-    return mrcnn_conv2d_wgrad_ex(d, x, gy, gw, ws, nullptr, nullptr, stream);
+    return mrcnn_conv2d_wgrad_ex(d, x, gy, gw, ws, nullptr, nullptr, nullptr, stream);
 }
 
 // ---- Deconvolution 2x2 stride 2 (= adjoint of a 2x2/2 convolution g: (N,2H,2W,K) -> (N,H,W,C)
@@ -992,7 +1051,7 @@ extern "C" int mrcnn_deconv2x2s2_fwd(const float *x, const float *w, const float
     p.gp = H; p.gq = W; p.sh = H; p.sw = W;
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.lda = C; p.ldb = 4 * K; p.ldc = K;
-    p.flags = epi_flags; p.out_mode = OUT_DECONV; p.ko = K;
+    p.flags = epi_flags; p.out_mode = OUT_DECONV; p.ko = K; p.prof_kind = mrcnn::PROF_CONV_FWD_128;
     if (int rc = set_extents(p, (int64_t)N * H * W * C, (int64_t)C * 4 * K, (int64_t)N * 4 * H * W * K))
         return rc;
     return launch<DGRAD>(p, 1, mrcnn::as_stream(stream));

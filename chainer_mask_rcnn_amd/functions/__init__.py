@@ -7,7 +7,7 @@ from .affine_channel_2d import AffineChannel2DFunction
 from .roi_align_2d import roi_align_2d
 from .roi_align_2d import ROIAlign2D
 
-from .conv import conv2d, deconv2x2s2, linear, stem_conv, bottleneck
+from .conv import conv2d, deconv2x2s2, linear, stem_conv, bottleneck, building_block
 from .pooling import max_pooling_2d, average_pooling_2d
 from .loss import (sigmoid_cross_entropy, softmax_cross_entropy, fast_rcnn_loc_loss,
                    mask_sigmoid_cross_entropy, softmax)

@@ -257,7 +257,13 @@ def _fwd_raw(x, Wc, d, scale, shift, residual, relu):
 USE_TRANSPOSED_DGRAD = True
 
 
-def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, accum=False):
+def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, accum=False,
+               out_mask_y=None, out_scale=None, fold_scale=None):
+    """gx = dgrad(g') with the fused pieces of include/mrcnn_hip.h "Extended backward entry
+    points": consumer-side ``mask_y`` / ``in_scale``, producer-side ``out_mask_y`` /
+    ``out_scale``, shortcut gradient ``res_g`` (masked by ``res_y`` if given).  ``fold_scale``
+    is a per-output-channel scale of the incoming gradient folded into the filter (stride 1)
+    or, for the strided kernel, passed as ``in_scale``."""
     gx = out if out is not None else empty_nhwc((d.N, d.C, d.H, d.W), g.device)
     if USE_TRANSPOSED_DGRAD and d.stride == 1 and d.R == d.S:
         # forward-form dgrad on the flipped, transposed filter (rebuilt per call: it moves
@@ -265,14 +271,18 @@ def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, acc
         nbytes = 4 * d.K * d.R * d.S * d.C
         wT = _lib.workspace(nbytes, g.device, 'wT')
         _lib.call('mrcnn_filter_flip_transpose', _lib.ptr(Wc), _lib.ptr(wT), d.K, d.R, d.S, d.C,
-                  _lib.stream_ptr())
+                  _lib.ptr(fold_scale), _lib.stream_ptr())
         _lib.call('mrcnn_conv2d_dgrad_wt', ctx_desc(d), _lib.ptr(g), _lib.ptr(wT), _lib.ptr(gx),
                   EPI_ACCUM if accum else 0, _lib.ptr(mask_y), _lib.ptr(in_scale),
-                  _lib.ptr(res_g), _lib.ptr(res_y), _lib.stream_ptr())
+                  _lib.ptr(res_g), _lib.ptr(res_y), _lib.ptr(out_mask_y), _lib.ptr(out_scale),
+                  _lib.stream_ptr())
         return gx
+    if fold_scale is not None:
+        assert in_scale is None
+        in_scale = fold_scale
     _lib.call('mrcnn_conv2d_dgrad_ex', ctx_desc(d), _lib.ptr(g), _lib.ptr(Wc), _lib.ptr(gx),
               EPI_ACCUM if accum else 0, _lib.ptr(mask_y), _lib.ptr(in_scale), _lib.ptr(res_g),
-              _lib.ptr(res_y), _lib.stream_ptr())
+              _lib.ptr(res_y), _lib.ptr(out_mask_y), _lib.ptr(out_scale), _lib.stream_ptr())
     return gx
 
 
@@ -299,7 +309,7 @@ def join_wgrad_stream(device=None):
             torch.cuda.current_stream(st.device).wait_stream(st)
 
 
-def _wgrad_raw(d, x, g, W, mask_y, in_scale, side=None):
+def _wgrad_raw(d, x, g, W, mask_y, in_scale, side=None, row_scale=None):
     """Returns the tensor autograd should see for W (None when written in place).  With
     ``side`` (a stream) the launch is queued there, ordered after everything queued so far
     on the current stream; only arena-backed (direct) gradients may use it."""
@@ -315,12 +325,13 @@ def _wgrad_raw(d, x, g, W, mask_y, in_scale, side=None):
                                 g.device, 'wgrad-side')
             _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(g),
                       _lib.ptr(gW), _lib.ptr(ws), _lib.ptr(mask_y), _lib.ptr(in_scale),
-                      _lib.stream_ptr())
+                      _lib.ptr(row_scale), _lib.stream_ptr())
         return None
     ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
                         g.device, 'wgrad')
     _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(g), _lib.ptr(gW),
-              _lib.ptr(ws), _lib.ptr(mask_y), _lib.ptr(in_scale), _lib.stream_ptr())
+              _lib.ptr(ws), _lib.ptr(mask_y), _lib.ptr(in_scale), _lib.ptr(row_scale),
+              _lib.stream_ptr())
     return None if direct else gW
 
 
@@ -385,3 +396,113 @@ def bottleneck(x, conv1, bn1, conv2, bn2, conv3, bn3, conv4=None, bn4=None, stri
         x, conv1.W, bn1.W, bn1.b, conv2.W, bn2.W, bn2.b, conv3.W, bn3.W, bn3.b,
         None if conv4 is None else conv4.W, None if bn4 is None else bn4.W,
         None if bn4 is None else bn4.b, stride)
+
+
+# ---------------------------------------------------------------------------------------
+# Whole-stage op: chainer BuildingBlock (BottleneckA + n x BottleneckB) as ONE autograd node.
+# Same launches as a chain of _BottleneckFn, but every gradient tensor inside the stage is
+# written ALREADY multiplied by the ReLU mask (and affine scale) of the conv that consumes it
+# — in the epilogue of the dgrad that produces it — so none of the stage's backward GEMMs
+# stages a mask: they all run the plain 168-register kernels, three workgroups per CU.  Only
+# the gradient entering the stage from autograd takes one elementwise masking pass.
+# ---------------------------------------------------------------------------------------
+class _StageFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, strides, proj, *params):
+        """``strides[i]`` / ``proj[i]``: conv1(/conv4) stride and has-projection flag of block
+        i; ``params``: per block W1,s1,b1,W2,s2,b2,W3,s3,b3 (+ W4,s4,b4 when proj[i])."""
+        _lib.require_device(x, params[0])
+        x = nhwc(x)
+        blocks, saved, pos = [], [x], 0
+        h = x
+        for stride, pj in zip(strides, proj):
+            n = 12 if pj else 9
+            W1, s1, b1, W2, s2, b2, W3, s3, b3 = params[pos:pos + 9]
+            W4, s4, b4 = params[pos + 9:pos + 12] if pj else (None, None, None)
+            d1 = make_desc(h.shape, W1.shape, stride, 0)
+            h1 = _fwd_raw(h, nhwc(W1), d1, s1, b1, None, True)
+            d2 = make_desc(h1.shape, W2.shape, 1, 1)
+            h2 = _fwd_raw(h1, nhwc(W2), d2, s2, b2, None, True)
+            d4 = None
+            if pj:
+                d4 = make_desc(h.shape, W4.shape, stride, 0)
+                shortcut = _fwd_raw(h, nhwc(W4), d4, s4, b4, None, False)
+            else:
+                shortcut = h
+            d3 = make_desc(h2.shape, W3.shape, 1, 0)
+            y = _fwd_raw(h2, nhwc(W3), d3, s3, b3, shortcut, True)
+            blocks.append(((d1, d2, d3, d4), (W1, W2, W3, W4), pos))
+            saved += [h1, h2, y, s1, s2, s3] + ([s4] if pj else [])
+            pos += n
+            h = y
+        ctx.blocks = blocks
+        ctx.proj = tuple(proj)
+        ctx.save_for_backward(*saved)
+        return h
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = list(ctx.saved_tensors)
+        ng = ctx.needs_input_grad
+        grads = [None] * len(ng)
+        # unpack per-block activations
+        acts, pos, xin = [], 1, saved[0]
+        for pj in ctx.proj:
+            n = 7 if pj else 6
+            h1, h2, y, s1, s2, s3 = saved[pos:pos + 6]
+            s4 = saved[pos + 6] if pj else None
+            acts.append((xin, h1, h2, y, s1, s2, s3, s4))
+            xin = y
+            pos += n
+        gy = nhwc(gy)
+        # gm: gradient w.r.t. the block output, already through that output's ReLU
+        gm = epilogue_bwd(gy, acts[-1][3], None)
+        for i in range(len(acts) - 1, -1, -1):
+            x, h1, h2, y, s1, s2, s3, s4 = acts[i]
+            (d1, d2, d3, d4), (W1, W2, W3, W4), p0 = ctx.blocks[i]
+            base = 3 + p0                      # index of W1 among the forward inputs
+            first = i == 0
+            # what the gradient leaving this block must be masked with: the previous block's
+            # output ReLU (= this block's input); the stage input belongs to someone else
+            xm = None if first else x
+            if ng[base + 6]:
+                grads[base + 6] = _wgrad_raw(d3, h2, gm, W3, None, None, row_scale=s3)
+            if W4 is not None and ng[base + 9]:
+                grads[base + 9] = _wgrad_raw(d4, x, gm, W4, None, None, row_scale=s4)
+            gh2 = _dgrad_raw(d3, gm, nhwc(W3), None, None, fold_scale=s3,
+                             out_mask_y=h2, out_scale=s2)
+            if ng[base + 3]:
+                grads[base + 3] = _wgrad_raw(d2, h1, gh2, W2, None, None)
+            gh1 = _dgrad_raw(d2, gh2, nhwc(W2), None, None, out_mask_y=h1, out_scale=s1)
+            if ng[base]:
+                grads[base] = _wgrad_raw(d1, x, gh1, W1, None, None)
+            if first and not ng[0]:
+                break
+            if W4 is None:
+                gm = _dgrad_raw(d1, gh1, nhwc(W1), None, None, res_g=gm, out_mask_y=xm)
+            elif d1.stride == 1:
+                gx = _dgrad_raw(d1, gh1, nhwc(W1), None, None)
+                gm = _dgrad_raw(d4, gm, nhwc(W4), None, None, fold_scale=s4, out=gx, accum=True,
+                                out_mask_y=xm)
+            else:
+                gx = _dgrad_raw(d1, gh1, nhwc(W1), None, None)
+                gm = _dgrad_raw(d4, gm, nhwc(W4), None, None, fold_scale=s4, out=gx, accum=True)
+                if xm is not None:
+                    gm = epilogue_bwd(gm, xm, None)
+        if ng[0]:
+            grads[0] = gm
+        return tuple(grads)
+
+
+def building_block(x, blocks, first_stride=None):
+    """A chain of Bottleneck links (chainer BuildingBlock) as one fused autograd node."""
+    strides, proj, params = [], [], []
+    for i, b in enumerate(blocks):
+        strides.append(b.conv1.stride if not (i == 0 and first_stride is not None) else first_stride)
+        proj.append(bool(b.projection))
+        params += [b.conv1.W, b.bn1.W, b.bn1.b, b.conv2.W, b.bn2.W, b.bn2.b,
+                   b.conv3.W, b.bn3.W, b.bn3.b]
+        if b.projection:
+            params += [b.conv4.W, b.bn4.W, b.bn4.b]
+    return _StageFn.apply(x, tuple(strides), tuple(proj), *params)

@@ -5,6 +5,8 @@ forward(imgs, bboxes, labels, masks, scales) -> scalar loss (sum of the five los
 the six reported scalars are kept in ``self.report`` (device tensors, no sync) as the
 reference reports them through chainer.reporter (:182-188).
 """
+import time
+
 import numpy as np
 import torch
 
@@ -14,6 +16,26 @@ from .utils import ProposalTargetCreator
 
 
 _POOL = None
+_COPY_STREAMS = {}
+
+
+def _upload(array, dtype, dev):
+    """Host array -> device tensor through a side stream.  A pageable host-to-device copy
+    issued on the compute stream blocks the host until everything queued there (e.g. the whole
+    head forward) has run; on its own stream it only waits for the copy itself, so the host
+    keeps preparing targets while the GPU computes.  The compute stream is ordered after it."""
+    if dev.type != 'cuda':
+        return torch.tensor(array, dtype=dtype, device=dev)
+    key = str(dev)
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    side = _COPY_STREAMS[key]
+    main = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        t = torch.tensor(array, dtype=dtype, device=dev)
+    main.wait_stream(side)
+    t.record_stream(main)
+    return t
 
 
 def _pool():
@@ -39,10 +61,15 @@ class MaskRCNNTrainChain(torch.nn.Module):
         self.report = {}
         self.features_grad_hook = None     # set by parallel.DataParallelGradSync
         self.mask_branch_fg_only = True
+        self.host_timeline = None          # developer aid: list of (label, perf_counter) marks
 
     def forward(self, imgs, bboxes, labels, masks, scales):
         """imgs (N,3,H,W) device tensor; bboxes / labels / masks: per-image sequences of
         host (or device) arrays (G,4) f32 / (G,) i32 / (G,H,W) i32; scales (N,) floats."""
+        tl = self.host_timeline
+        mark = (lambda label: tl.append((label, time.perf_counter()))) if tl is not None \
+            else (lambda label: None)
+        mark('begin')
         scales = np.asarray([float(s) for s in scales], dtype=np.float32)
         to_np = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
         bboxes = [to_np(b).astype(np.float32) for b in bboxes]
@@ -68,8 +95,10 @@ class MaskRCNNTrainChain(torch.nn.Module):
             features, img_size, scales)
 
         # proposal targets: host-side sampling, exactly as the reference (:126-146)
+        mark('extractor+rpn queued')
         rois_h = rois.cpu().numpy()
         roi_indices_h = roi_indices.cpu().numpy()
+        mark('rois on host')
         ptc = self.proposal_target_creator
         split = hasattr(ptc, 'sample') and hasattr(ptc, 'mask_targets')
         sample_rois, sample_roi_indices = [], []
@@ -87,7 +116,7 @@ class MaskRCNNTrainChain(torch.nn.Module):
             sample_roi_indices.append(np.full((len(sample_roi),), batch_index, dtype=np.int32))
             gt_roi_locs.append(gt_roi_loc)
             gt_roi_labels.append(gt_roi_label)
-        up = lambda parts, dt: torch.tensor(np.concatenate(parts, axis=0), dtype=dt, device=dev)
+        up = lambda parts, dt: _upload(np.concatenate(parts, axis=0), dt, dev)
         gt_roi_labels_h = np.concatenate(gt_roi_labels, axis=0)
         sample_rois = up(sample_rois, torch.float32)
         sample_roi_indices = up(sample_roi_indices, torch.int32)
@@ -99,6 +128,7 @@ class MaskRCNNTrainChain(torch.nn.Module):
         # neither to the loss nor to any gradient.  With
         # ``mask_branch_fg_only`` the branch runs on the foreground rows only: identical loss
         # (same normaliser: the count of non-ignored target pixels) and identical gradients.
+        mark('rois sampled')
         mask_rows = None
         if self.mask_branch_fg_only:
             fg_rows = np.flatnonzero(gt_roi_labels_h > 0)
@@ -107,10 +137,12 @@ class MaskRCNNTrainChain(torch.nn.Module):
         roi_cls_locs, roi_scores, roi_masks = self.mask_rcnn.head(
             features, sample_rois, sample_roi_indices, mask_rows=mask_rows)
 
+        mark('head queued')
         # the head is now queued on the GPU: build the 14x14 mask targets on the host meanwhile
         if split:
             gt_roi_masks = [ptc.mask_targets(job, to_np(mask)) for job, mask in mask_jobs]
         gt_roi_masks = up(gt_roi_masks, torch.int32)
+        mark('mask targets')
 
         # RPN targets (host) — after all ProposalTargetCreator calls, as in the reference,
         # so the global np.random stream is consumed in the same order (:150-158).
@@ -124,6 +156,7 @@ class MaskRCNNTrainChain(torch.nn.Module):
             gt_rpn_labels.append(gt_rpn_label)
         gt_rpn_locs = up(gt_rpn_locs, torch.float32)
         gt_rpn_labels = up(gt_rpn_labels, torch.int32)
+        mark('rpn targets')
         rpn_locs = rpn_locs.reshape(-1, 4)
         rpn_scores = rpn_scores.reshape(-1)
         rpn_loc_loss = F.fast_rcnn_loc_loss(rpn_locs, gt_rpn_locs, gt_rpn_labels, self.rpn_sigma)
@@ -150,6 +183,7 @@ class MaskRCNNTrainChain(torch.nn.Module):
                        'roi_cls_loss': roi_cls_loss.detach(),
                        'roi_mask_loss': roi_mask_loss.detach(),
                        'loss': loss.detach()}
+        mark('losses queued')
         self.last_targets = {'sample_rois': sample_rois, 'gt_roi_labels': gt_roi_labels,
                              'n_rois': int(sample_rois.shape[0])}
         return loss

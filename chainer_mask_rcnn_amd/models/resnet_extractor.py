@@ -80,7 +80,12 @@ class Bottleneck(torch.nn.Module):
 
 
 class BuildingBlock(torch.nn.Module):
-    """chainer BuildingBlock(n_layer, in, mid, out, stride): children a, b1 .. b{n-1}."""
+    """chainer BuildingBlock(n_layer, in, mid, out, stride): children a, b1 .. b{n-1}.
+
+    ``fused_stage`` (default): the whole stage is one autograd node whose backward GEMMs
+    need no mask staging (functions/conv.py:_StageFn); False chains per-bottleneck nodes.
+    """
+    fused_stage = True
 
     def __init__(self, n_layer, in_ch, mid_ch, out_ch, stride):
         super(BuildingBlock, self).__init__()
@@ -94,6 +99,8 @@ class BuildingBlock(torch.nn.Module):
     def forward(self, x, first_stride=None):
         """``first_stride`` overrides the stride of block ``a`` (used by the RoI head when the
         stride-2 subsampling has already been done by the pooling op)."""
+        if self.fused_stage:
+            return F.building_block(x, [getattr(self, n) for n in self._names], first_stride)
         for name in self._names:
             if name == 'a' and first_stride is not None:
                 x = self.a(x, stride=first_stride)

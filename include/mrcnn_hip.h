@@ -152,29 +152,44 @@ int mrcnn_conv2d_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w
 int64_t mrcnn_conv2d_wgrad_workspace_bytes(const mrcnn_conv_desc *d);
 int mrcnn_conv2d_wgrad(const mrcnn_conv_desc *d, const float *x, const float *gy,
                        float *gw, void *ws, void *stream);
-/* Extended backward entry points with the producing conv's epilogue backward fused into
- * the operand staging — g = gy * (mask_y > 0) * in_scale[k] is formed in registers on the
- * way to LDS, so no elementwise pass over gy is needed (mask_y: output of the ReLU that
- * followed the conv, same shape as gy; in_scale: its AffineChannel2D scale (K); either may
- * be NULL).  dgrad additionally adds the identity-shortcut gradient of a bottleneck in its
- * epilogue: gx += res_g * (res_y > 0) (both (N,H,W,C) or NULL; stride 1 only). */
+/* Extended backward entry points.  The backward of a conv's fused epilogue (AffineChannel2D
+ * scale s[k], then ReLU with output y) can be applied at either end of the gradient tensor:
+ *
+ *  consumer side — while gy is staged into LDS: g = gy * (mask_y > 0) * in_scale[k]
+ *      (mask_y: output of the ReLU that followed THIS conv, same shape as gy; in_scale: its
+ *      affine scale (K); either may be NULL).  Costs 16 more registers per lane, so these
+ *      variants run two workgroups per CU.
+ *  producer side — in the dgrad epilogue that WRITES the gradient:
+ *      gx = (acc * out_scale[c] + res_g * (res_y > 0)) * (out_mask_y > 0)
+ *      out_mask_y / out_scale: ReLU output / affine scale of the conv that produced this
+ *      conv's INPUT ((N,H,W,C) / (C); either may be NULL).  The next dgrad / wgrad down the
+ *      chain then need no mask and run the plain, three-workgroups-per-CU kernels.
+ *      res_g (+ optional res_y): identity-shortcut gradient of a bottleneck, (N,H,W,C);
+ *      stride 1 only.  With MRCNN_EPI_ACCUM the previous gx is added before the mask.
+ *  A per-output-channel scale that cannot go to the producer (the block-top gradient feeds
+ *  conv3, conv4 and the shortcut with different scales) is folded into the filter for dgrad
+ *  (row_scale of mrcnn_filter_flip_transpose) and applied to the rows of gw in the wgrad
+ *  epilogue (out_row_scale): gw[k] = s[k] * sum_m gy[m,k] x[m].
+ * Used by functions/conv.py:_StageFn (a whole ResNet stage as one autograd node) and
+ * _BottleneckFn; chainer runs each of these as separate elementwise kernels. */
 int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, const float *w,
                           float *gx, int epi_flags, const float *mask_y,
                           const float *in_scale, const float *res_g, const float *res_y,
-                          void *stream);
+                          const float *out_mask_y, const float *out_scale, void *stream);
 int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float *gy,
                           float *gw, void *ws, const float *mask_y, const float *in_scale,
-                          void *stream);
+                          const float *out_row_scale, void *stream);
 /* Stride-1 dgrad expressed as a forward-form convolution of gy with the flipped, transposed
- * filter wT[c][R-1-r][S-1-s][k] = w[k][r][s][c] (both GEMM operands K-contiguous: ~6 % faster
- * than mrcnn_conv2d_dgrad_ex).  mrcnn_filter_flip_transpose builds wT (C,R,S,K) from w (K,R,S,C);
- * it moves R*S*K*C*8 bytes, negligible next to the dgrad. Same extra arguments as _ex. */
+ * filter wT[c][R-1-r][S-1-s][k] = w[k][r][s][c] * row_scale[k] (both GEMM operands
+ * K-contiguous).  mrcnn_filter_flip_transpose builds wT (C,R,S,K) from w (K,R,S,C)
+ * (row_scale (K) or NULL); it moves R*S*K*C*8 bytes, negligible next to the dgrad.
+ * Same extra arguments as _ex. */
 int mrcnn_filter_flip_transpose(const float *w, float *wT, int K, int R, int S, int C,
-                                void *stream);
+                                const float *row_scale, void *stream);
 int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, const float *wT,
                           float *gx, int epi_flags, const float *mask_y,
                           const float *in_scale, const float *res_g, const float *res_y,
-                          void *stream);
+                          const float *out_mask_y, const float *out_scale, void *stream);
 /* Stem: conv1 7x7/2 pad 3 with bias of chainer ResNet50Layers (SURVEY.md A.1;
  * models/resnet_extractor.py:65-67) fused with bn1-as-affine and ReLU.  x4 is
  * the image padded to 4 channels (N,H,W,4); w784 is the filter laid out

@@ -223,3 +223,48 @@ def test_fused_bottleneck_matches_oracle(dev, proj, stride):
     _close(blk.conv1.W.grad.cpu().numpy(), gW1)
     _close(blk.conv2.W.grad.cpu().numpy(), gW2)
     _close(blk.conv3.W.grad.cpu().numpy(), gW3)
+
+
+@pytest.mark.parametrize('shape,chans,stride', [
+    ((3, 13, 10), (64, 32, 128), 2),       # 64x64 tiles, strided projection block
+    ((2, 23, 17), (64, 32, 128), 1),
+    ((2, 160, 160), (128, 128, 256), 1),   # 128x128 tiles (three workgroups per CU)
+])
+def test_fused_stage_matches_bottleneck_chain(dev, shape, chans, stride):
+    """_StageFn (producer-side masks: no backward GEMM stages a mask) vs the chain of
+    per-bottleneck nodes, which test_fused_bottleneck_matches_oracle pins to the oracle."""
+    from chainer_mask_rcnn_amd.models.resnet_extractor import BuildingBlock
+    torch.manual_seed(3)
+    n, h, w = shape
+    cin, mid, cout = chans
+    stage = BuildingBlock(3, cin, mid, cout, stride).to(dev)
+    with torch.no_grad():
+        for name, p in stage.named_parameters():
+            if '.bn' in name and name.endswith('.W'):
+                p.uniform_(0.5, 1.5)
+            elif '.bn' in name:
+                p.normal_(0, 0.3)
+    x = torch.randn((n, cin, h, w), device=dev)
+    gy = None
+    out = {}
+    for fused in (False, True):
+        stage.fused_stage = fused
+        for p in stage.parameters():
+            p.grad = None
+        xt = x.clone().requires_grad_(True)
+        y = stage(xt)
+        if gy is None:
+            gy = torch.randn_like(y)
+        y.backward(gy)
+        out[fused] = (y.detach(), xt.grad, {k: p.grad.clone() for k, p in stage.named_parameters()
+                                            if p.grad is not None})
+    ya, gxa, ga = out[False]
+    yb, gxb, gb = out[True]
+    assert torch.equal(ya, yb)             # same forward launches
+    _close(gxb.cpu().numpy(), gxa.cpu().numpy())
+    assert set(ga) == set(gb) and any(k.endswith('conv4.W') for k in ga)
+    for k in ga:
+        _close(gb[k].cpu().numpy(), ga[k].cpu().numpy())
+    # the stage input is not masked by the stage (its ReLU belongs to the producer): a
+    # negative input pixel still receives gradient
+    assert (gxb[x <= 0].abs() > 0).any()

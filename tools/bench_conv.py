@@ -47,7 +47,7 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None
     lib = _lib.load()
     tot = {'fwd': 0., 'dgrad': 0., 'wgrad': 0.}
-    print('%-28s %9s %9s %9s   (TFLOP/s | ms)' % ('shape', 'fwd', 'dgrad', 'wgrad'))
+    print('%-28s %11s %11s %11s %11s  (TFLOP/s | ms)' % ('shape', 'fwd', 'dgrad', 'wgrad', 'dgrad_wt'))
     for name, N, C, H, W, K, k, s, p in SHAPES:
         if only and only not in name:
             continue
@@ -71,13 +71,33 @@ def main():
             ymask = torch.randn((d.N, d.P, d.Q, d.K), device=dev).permute(0, 3, 1, 2)
             sc = torch.rand((d.K,), device=dev) + 0.5
             g = lambda: _lib.call('mrcnn_conv2d_dgrad_ex', ctx_desc(d), _lib.ptr(gy), _lib.ptr(w),
-                                  _lib.ptr(gx), 0, _lib.ptr(ymask), _lib.ptr(sc), None, None, sp)
+                                  _lib.ptr(gx), 0, _lib.ptr(ymask), _lib.ptr(sc), None, None, None, None, sp)
             h = lambda: _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(gy),
-                                  _lib.ptr(gw), _lib.ptr(ws), _lib.ptr(ymask), _lib.ptr(sc), sp)
+                                  _lib.ptr(gw), _lib.ptr(ws), _lib.ptr(ymask), _lib.ptr(sc), None, sp)
         tf, tg, th = timeit(f), timeit(g), timeit(h)
         tot['fwd'] += tf; tot['dgrad'] += tg; tot['wgrad'] += th
-        print('%-28s %5.1f|%5.2f %5.1f|%5.2f %5.1f|%5.2f' % (
-            name, flop / tf / 1e9, tf, flop / tg / 1e9, tg, flop / th / 1e9, th))
+        tt = float('nan')
+        if s == 1:
+            # forward-form dgrad on the flipped/transposed filter, masked + scaled (what a
+            # bottleneck backward launches for its stride-1 convolutions)
+            ymask = torch.randn((d.N, d.P, d.Q, d.K), device=dev).permute(0, 3, 1, 2)
+            sc = torch.rand((d.K,), device=dev) + 0.5
+            wT = torch.empty((C * k * k * K,), device=dev)
+            _lib.call('mrcnn_filter_flip_transpose', _lib.ptr(w), _lib.ptr(wT), K, k, k, C, None, sp)
+            if os.environ.get('BENCH_MASK'):   # consumer-side mask staging
+                t = lambda: _lib.call('mrcnn_conv2d_dgrad_wt', ctx_desc(d), _lib.ptr(gy), _lib.ptr(wT),
+                                      _lib.ptr(gx), 0, _lib.ptr(ymask), _lib.ptr(sc), None, None,
+                                      None, None, sp)
+            else:                              # producer-side: mask + scale in the epilogue
+                xm = torch.randn((N, H, W, C), device=dev).permute(0, 3, 1, 2)
+                sc = torch.rand((C,), device=dev) + 0.5
+                t = lambda: _lib.call('mrcnn_conv2d_dgrad_wt', ctx_desc(d), _lib.ptr(gy), _lib.ptr(wT),
+                                      _lib.ptr(gx), 0, None, None, None, None, _lib.ptr(xm),
+                                      _lib.ptr(sc), sp)
+            tt = timeit(t)
+        print('%-28s %5.1f|%5.2f %5.1f|%5.2f %5.1f|%5.2f %5.1f|%5.2f' % (
+            name, flop / tf / 1e9, tf, flop / tg / 1e9, tg, flop / th / 1e9, th,
+            flop / tt / 1e9, tt))
     print('sum ms', tot)
 
 
