@@ -131,7 +131,9 @@ def pmc_traffic(kernel_name):
     if not m:
         return None
     mode = {'FWD': 0, 'DGRAD': 1, 'WGRAD': 2}[m.group(3)]
-    key = 'conv_gemm_kernel<%s, %s, %d>' % (m.group(1), m.group(2), mode)
+    # forward-form launches (fwd and the transposed-filter dgrad) share one kernel symbol;
+    # the unmasked variant (<.., false, false>) is what the train step runs
+    key = 'conv_gemm_kernel<%s, %s, %d, false' % (m.group(1), m.group(2), 0 if mode == 1 else mode)
     with open(files[-1]) as f:
         data = json.load(f)
     for k, v in data.items():

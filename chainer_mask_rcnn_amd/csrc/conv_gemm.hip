@@ -200,12 +200,17 @@ conv_gemm_kernel(const GemmParams p)
     // tile -> (m0, n0).  Workgroup b runs on XCD b % 8 (observed dispatch order); remap so
     // that each XCD owns a contiguous run of tile ids — N fastest — and neighbouring tiles,
     // which share the gathered A rows and the filter panel, hit the same private L2.
+    // WGRAD (grid = tiles x splits): the remap runs over the whole 2-D grid with the split as
+    // the slow index, so the tiles of one split — which all stream the same pixel range of gy
+    // and x — land on one or two XCDs instead of all eight.
     const int ntn = (p.N + BN - 1) / BN;
-    int tile = blockIdx.x;
+    int tile = blockIdx.x + blockIdx.y * gridDim.x;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+        const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int split = tile / (int)gridDim.x;
+    tile -= split * (int)gridDim.x;
     if (PP) tile = 2 * tile + grp;   // a surplus tile lies beyond M: all its accesses are OOB
     const int m0 = p.m_lo + (tile / ntn) * BM;
     const int n0 = (tile % ntn) * BN;
@@ -245,7 +250,7 @@ conv_gemm_kernel(const GemmParams p)
         wc = jj - rs * p.cin;
         wr = rs / p.S;
         ws_ = rs - wr * p.S;
-        k_begin = blockIdx.y * p.split_len;
+        k_begin = split * p.split_len;
         k_end = min(p.Kc, k_begin + p.split_len);
 #pragma unroll
         for (int i = 0; i < BV; ++i) {
@@ -544,7 +549,7 @@ conv_gemm_kernel(const GemmParams p)
     // Per 32x32 MFMA tile: compute the 16 element offsets, issue every auxiliary load
     // (residual / accumulate / shortcut gradient) back to back, then combine and store.
     const float *out_base = p.C;
-    if (MODE == WGRAD) out_base += (int64_t)blockIdx.y * p.split_stride;
+    if (MODE == WGRAD) out_base += (int64_t)split * p.split_stride;
     const __amdgpu_buffer_rsrc_t rC = make_rsrc(out_base, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rRes = make_rsrc(p.residual, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rResG = make_rsrc(p.res_g, p.c_bytes);

@@ -9,6 +9,7 @@ from .roi_align_2d import ROIAlign2D
 
 from .conv import conv2d, deconv2x2s2, linear, stem_conv, bottleneck, building_block
 from .pooling import max_pooling_2d, average_pooling_2d
+from .rows import fanout_rows
 from .loss import (sigmoid_cross_entropy, softmax_cross_entropy, fast_rcnn_loc_loss,
                    mask_sigmoid_cross_entropy, softmax)
 from .proposal_ops import non_maximum_suppression

@@ -92,13 +92,18 @@ class ResNetRoIHead(torch.nn.Module):
             res5 = self.res5(pool)
 
         roi_cls_locs = roi_scores = roi_masks = None
+        res5_fg = None
+        if pred_bbox and pred_mask and mask_rows is not None:
+            res5, res5_fg = F.fanout_rows(res5, mask_rows)
         if pred_bbox:
             pool5 = F.average_pooling_2d(res5, 7, stride=7)
             fc = F.linear(pool5, self.cls_loc_score.W, self.cls_loc_score.b)
             roi_cls_locs = fc[:, :4 * self.n_class]
             roi_scores = fc[:, 4 * self.n_class:5 * self.n_class]
         if pred_mask:
-            if mask_rows is not None:
+            if res5_fg is not None:
+                res5 = res5_fg
+            elif mask_rows is not None:
                 res5 = res5.index_select(0, mask_rows)
             deconv6 = F.deconv2x2s2(res5, self.deconv6.W, self.deconv6.b, relu=True)
             roi_masks = self.mask(deconv6)
