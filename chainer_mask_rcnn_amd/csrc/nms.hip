@@ -79,8 +79,13 @@ __device__ __forceinline__ uint64_t readfirstlane64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
-// grid (groups), block 256, dynamic LDS = nblk_max * 8 bytes.
-__global__ void __launch_bounds__(256)
+// grid (groups), block 64 * W (W = 4 or 16 waves), dynamic LDS = nblk_max * 8 bytes.
+// Per 64-row chunk: wave 0 resolves the in-chunk dependency from the 64 diagonal words (the
+// next chunk's diagonal is already in flight), then every wave ORs "its" kept rows (row j
+// belongs to wave j mod W, so at most 64 / W row loads per lane, all issued back to back)
+// into the removed bit-vector with LDS atomics.  The chain per chunk is one global round
+// trip, not one per kept row.
+__global__ void __launch_bounds__(1024)
 nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict__ n_dev,
                 int n_max, int nblk_max, int limit, int32_t *__restrict__ keep_all,
                 int32_t *__restrict__ n_keep_all)
@@ -89,19 +94,23 @@ nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict
     __shared__ uint64_t s_kept;
     __shared__ int s_count;
     const int g = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint64_t *__restrict__ mask = mask_all + (int64_t)g * n_max * nblk_max;
     int32_t *__restrict__ keep = keep_all + (int64_t)g * n_max;
     const int n = min(n_dev ? n_dev[g] : n_max, n_max);
     const int nblk = (n + 63) / 64;
     for (int c = tid; c < nblk; c += blockDim.x) removed[c] = 0;
     if (tid == 0) s_count = 0;
+    // rows this wave ORs in: bits j with j % nwaves == wave
+    uint64_t mine = 0;
+    for (int j = wave; j < 64; j += nwaves) mine |= 1ull << j;
+    uint64_t diag = 0;
+    if (wave == 0 && lane < n) diag = mask[(int64_t)lane * nblk_max];
     __syncthreads();
 
     for (int blk = 0; blk < nblk; ++blk) {
-        if (tid < 64) {
-            const int row = blk * 64 + tid;
-            const uint64_t diag = row < n ? mask[(int64_t)row * nblk_max + blk] : 0ull;
+        if (wave == 0) {
+            const int row = blk * 64 + lane;
             uint64_t rem = readfirstlane64(removed[blk]);
             const int nrow = n - blk * 64;
             if (nrow < 64) rem |= ~((1ull << nrow) - 1ull);
@@ -114,14 +123,17 @@ nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict
                     rem |= dj;
                 }
             }
+            // next chunk's diagonal words: in flight across the barrier and the OR phase
+            const int nrow_next = row + 64;
+            diag = (blk + 1 < nblk && nrow_next < n) ? mask[(int64_t)nrow_next * nblk_max + blk + 1] : 0ull;
             const int cnt = s_count;
             if (limit > 0) {
                 int room = limit - cnt;
                 while (__popcll(kept) > room) kept &= ~(1ull << (63 - __clzll((long long)kept)));
             }
-            if ((kept >> tid) & 1ull)
-                keep[cnt + __popcll(kept & ((1ull << tid) - 1ull))] = row;
-            if (tid == 0) {
+            if ((kept >> lane) & 1ull)
+                keep[cnt + __popcll(kept & ((1ull << lane) - 1ull))] = row;
+            if (lane == 0) {
                 s_kept = kept;
                 s_count = cnt + __popcll(kept);
             }
@@ -130,11 +142,12 @@ nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict
         const uint64_t kept = s_kept;
         const int cnt = s_count;
         if (limit > 0 && cnt >= limit) break;
-        if (kept) {
+        const uint64_t k_mine = kept & mine;
+        if (k_mine) {
             const uint64_t *__restrict__ rows = mask + (int64_t)blk * 64 * nblk_max;
-            for (int c = blk + 1 + tid; c < nblk; c += blockDim.x) {
-                uint64_t acc = removed[c];
-                uint64_t k = kept;
+            for (int c = blk + 1 + lane; c < nblk; c += 64) {
+                uint64_t acc = 0;
+                uint64_t k = k_mine;
                 while (k) {
                     // up to four independent row loads in flight
                     const int j0 = __ffsll((long long)k) - 1; k &= k - 1;
@@ -144,7 +157,7 @@ nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict
                     if (k) { const int j3 = __ffsll((long long)k) - 1; k &= k - 1; m3 = rows[(int64_t)j3 * nblk_max + c]; }
                     acc |= (m0 | m1) | (m2 | m3);
                 }
-                removed[c] = acc;
+                if (acc) atomicOr(reinterpret_cast<unsigned long long *>(&removed[c]), (unsigned long long)acc);
             }
         }
         __syncthreads();
@@ -184,7 +197,9 @@ extern "C" int mrcnn_nms_sorted_batched(const float *bbox, const int32_t *n_dev,
                            (const float4 *)bbox, n_dev, n_max, nblk, thresh, (uint64_t *)mask_ws);
     }
     mrcnn::ProfScope prof(mrcnn::PROF_NMS_SCAN, 0., (double)groups * n_max * 4.0 * nblk, s);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(groups), dim3(256), (size_t)nblk * 8, s,
+    // long problems (RPN: 12000 boxes, 2 groups) get 16 waves, short batched ones (per-class
+    // NMS: <= 1000 boxes, hundreds of groups) 4
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(groups), dim3(nblk > 32 ? 1024 : 256), (size_t)nblk * 8, s,
                        (const uint64_t *)mask_ws, n_dev, n_max, nblk, limit, keep, n_keep);
     return mrcnn::check_launch("nms_sorted");
 }
