@@ -55,10 +55,24 @@ constexpr bool USE_PINGPONG = MRCNN_GEMM_PINGPONG != 0;
 #ifndef MRCNN_GEMM_SINGLEBUF_WGRAD
 #define MRCNN_GEMM_SINGLEBUF_WGRAD 1
 #endif
+#ifndef MRCNN_GEMM_MINWAVES
+#define MRCNN_GEMM_MINWAVES 1
+#endif
+#ifndef MRCNN_GEMM_SINGLEBUF_SMALL
+#define MRCNN_GEMM_SINGLEBUF_SMALL 1
+#endif
 constexpr bool single_buffered(int tm, int mode, bool masked)
 {
+    if (tm == 1) return MRCNN_GEMM_SINGLEBUF_SMALL != 0 && !masked && mode == 0;
     return MRCNN_GEMM_SINGLEBUF != 0 && tm == 2 && !masked &&
            (mode == 0 || (mode == 2 && MRCNN_GEMM_SINGLEBUF_WGRAD != 0));
+}
+// minimum workgroups per CU the register allocation must allow (256-thread workgroups: one
+// wave per SIMD each)
+constexpr int min_blocks(int tm, int mode, bool masked)
+{
+    if (!single_buffered(tm, mode, masked)) return MRCNN_GEMM_MINWAVES;
+    return tm == 2 ? 3 : 6;
 }
 constexpr int KPAD = 4;  // K-contiguous LDS rows are 36 floats (conflict-free b128)
 
@@ -162,9 +176,6 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
     return make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
 }
 
-#ifndef MRCNN_GEMM_MINWAVES
-#define MRCNN_GEMM_MINWAVES 1
-#endif
 // PP ("ping-pong"): a 512-thread workgroup runs TWO independent output tiles, one per group of
 // four waves, in antiphase: while one group issues its 64 MFMAs per K slice the other group
 // does everything else (wait for its global loads, write them to LDS, issue the next loads),
@@ -175,7 +186,7 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
 // one wave per SIMD cannot keep the fp32 MFMA pipe as full as two interleaved waves do.  Kept
 // as a compile-time experiment (-DMRCNN_GEMM_PINGPONG=1), off by default.
 template <int TM, int TN, int MODE, bool MASKED, bool PP>
-__global__ void __launch_bounds__(PP ? 512 : 256, single_buffered(TM, MODE, MASKED) ? 3 : MRCNN_GEMM_MINWAVES)
+__global__ void __launch_bounds__(PP ? 512 : 256, min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     constexpr bool SINGLEBUF = single_buffered(TM, MODE, MASKED) && !PP;
