@@ -53,50 +53,103 @@ __device__ __forceinline__ uint64_t make_key(float s, int idx)
     return ((uint64_t)b << 32) | (uint32_t)(~(uint32_t)idx);
 }
 
+// ---- exact stable top-k by bucketed rank ------------------------------------------------
+// rank(key) = #{keys larger}.  Keys are bucketed by their top 16 bits (sign/exponent/7
+// mantissa bits of the score): a histogram + a descending scan give every bucket its first
+// rank, a counting-sort pass groups the keys of a bucket, and each key then only counts the
+// larger keys inside its own bucket.  O(n + sum bucket^2) instead of O(n^2) compares (n =
+// 64 260 anchors: 0.24 ms -> tens of microseconds); the result is a pure function of the keys
+// (unique: the index is part of the key), so it does not depend on the atomics' order.
+constexpr int kBuckets = 1 << 16;
+constexpr int kRankSplits = 8;   // a bucket's compare loop is split 8 ways (degenerate inputs:
+                                 // all scores equal -> one bucket of n keys)
+
 __global__ void topk_keys_kernel(const float *__restrict__ score,
                                  const uint8_t *__restrict__ valid, int n,
-                                 uint64_t *__restrict__ keys, int32_t *__restrict__ n_valid)
+                                 uint64_t *__restrict__ keys, int32_t *__restrict__ hist,
+                                 int32_t *__restrict__ n_valid)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool v = false;
     if (i < n) {
         v = valid ? (valid[i] != 0) : true;
-        keys[i] = v ? make_key(score[i], i) : 0ull;
+        const uint64_t key = v ? make_key(score[i], i) : 0ull;
+        keys[i] = key;
+        atomicAdd(&hist[(int)(key >> 48)], 1);
     }
     const unsigned long long b = __ballot(v);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, (int)__popcll(b));
 }
 
-// rank[i] = #{j : key_j > key_i}.  Grid (i-blocks, j-splits): every workgroup counts its
-// 256 keys against one slice of the key array (read with wave-uniform scalar loads, 32 keys
-// in flight) and adds the partial count to rank[i]; the j-split multiplies the number of
-// resident waves so the scalar-load latency is hidden.
-__global__ void __launch_bounds__(256)
-topk_rank_kernel(const uint64_t *__restrict__ keys, int n, int chunk, int32_t *__restrict__ rank)
+// start[b] = number of keys in buckets above b (one workgroup of 1024 threads)
+__global__ void __launch_bounds__(1024)
+topk_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ start)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t ki = i < n ? keys[i] : ~0ull;
-    const int j0 = blockIdx.y * chunk;
-    const int j1 = min(n, j0 + chunk);
-    int cnt = 0;
-    int j = j0;
-    for (; j + 32 <= j1; j += 32) {
-#pragma unroll
-        for (int u = 0; u < 32; ++u) cnt += keys[j + u] > ki;
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    constexpr int PER = kBuckets / 1024;
+    // thread t owns buckets [hi - PER + 1, hi], hi descending with t
+    const int hi = kBuckets - 1 - t * PER;
+    int sum = 0;
+    for (int j = 0; j < PER; ++j) sum += hist[hi - j];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
     }
-    for (; j < j1; ++j) cnt += keys[j] > ki;
-    if (i < n && cnt) atomicAdd(&rank[i], cnt);
+    int run = part[t] - sum;       // exclusive prefix over the threads before t
+    for (int j = 0; j < PER; ++j) {
+        start[hi - j] = run;
+        run += hist[hi - j];
+    }
 }
 
-__global__ void topk_scatter_kernel(const uint64_t *__restrict__ keys,
+// counting sort by bucket (order inside a bucket is arbitrary); consumes hist
+__global__ void topk_place_kernel(const uint64_t *__restrict__ keys, int n,
+                                  int32_t *__restrict__ hist, const int32_t *__restrict__ start,
+                                  uint64_t *__restrict__ sorted)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    const int b = (int)(key >> 48);
+    sorted[start[b] + atomicSub(&hist[b], 1) - 1] = key;
+}
+
+// grid (n / 256, kRankSplits): within-bucket count of larger keys, slice blockIdx.y
+__global__ void __launch_bounds__(256)
+topk_rank_kernel(const uint64_t *__restrict__ sorted, const int32_t *__restrict__ start, int n,
+                 int32_t *__restrict__ rank)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t key = sorted[p];
+    const int b = (int)(key >> 48);
+    const int s = start[b], e = b > 0 ? start[b - 1] : n;
+    const int len = (e - s + kRankSplits - 1) / kRankSplits;
+    const int q0 = s + (int)blockIdx.y * len, q1 = min(e, q0 + len);
+    int cnt = 0;
+    for (int q = q0; q < q1; ++q) cnt += sorted[q] > key;
+    if (cnt) atomicAdd(&rank[p], cnt);
+}
+
+__global__ void topk_scatter_kernel(const uint64_t *__restrict__ sorted,
+                                    const int32_t *__restrict__ start,
                                     const int32_t *__restrict__ rank, int n, int k,
                                     int32_t *__restrict__ order,
                                     const int32_t *__restrict__ n_valid,
                                     int32_t *__restrict__ n_out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *n_out = min(k, *n_valid);
-    if (i < n && keys[i] != 0ull && rank[i] < k) order[rank[i]] = i;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) *n_out = min(k, *n_valid);
+    if (p >= n) return;
+    const uint64_t key = sorted[p];
+    if (key == 0ull) return;
+    const int r = start[(int)(key >> 48)] + rank[p];
+    if (r < k) order[r] = (int32_t)(~(uint32_t)key);
 }
 
 __global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx,
@@ -157,7 +210,10 @@ extern "C" int mrcnn_decode_clip(const float *anchor, const float *loc, float *r
     return mrcnn::check_launch("decode_clip");
 }
 
-extern "C" int64_t mrcnn_topk_workspace_bytes(int n) { return (int64_t)n * 12 + 128; }
+extern "C" int64_t mrcnn_topk_workspace_bytes(int n)
+{
+    return (int64_t)n * 20 + 2 * (int64_t)kBuckets * 4 + 256;
+}
 
 extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, int k,
                                int32_t *order, int32_t *n_out, void *ws, void *stream)
@@ -169,25 +225,29 @@ extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, 
         if (n_out) MRCNN_HIP_TRY(hipMemsetAsync(n_out, 0, 4, s));
         return 0;
     }
-    // workspace: [n_valid | pad to 64 B][rank n x i32][pad][keys n x u64]
-    int32_t *n_valid = (int32_t *)ws;
-    int32_t *rank = (int32_t *)((char *)ws + 64);
-    const size_t keys_off = 64 + (((size_t)n * 4 + 63) / 64) * 64;
-    uint64_t *keys = (uint64_t *)((char *)ws + keys_off);
-    MRCNN_HIP_TRY(hipMemsetAsync(ws, 0, keys_off, s));
+    // workspace: [n_valid | pad to 64 B][rank n x i32][pad][hist 64K x i32] (zeroed) then
+    // [start 64K x i32][keys n x u64][sorted n x u64]
+    char *w = (char *)ws;
+    int32_t *n_valid = (int32_t *)w;
+    int32_t *rank = (int32_t *)(w + 64);
+    const size_t hist_off = 64 + (((size_t)n * 4 + 63) / 64) * 64;
+    int32_t *hist = (int32_t *)(w + hist_off);
+    const size_t start_off = hist_off + (size_t)kBuckets * 4;
+    int32_t *start = (int32_t *)(w + start_off);
+    uint64_t *keys = (uint64_t *)(w + start_off + (size_t)kBuckets * 4);
+    uint64_t *sorted = keys + n;
+    MRCNN_HIP_TRY(hipMemsetAsync(ws, 0, start_off, s));
     const int blocks = (int)mrcnn::ceil_div(n, 256);
-    hipLaunchKernelGGL(topk_keys_kernel, dim3(blocks), dim3(256), 0, s, score, valid, n, keys,
+    mrcnn::ProfScope prof(mrcnn::PROF_TOPK, 0., 40.0 * n + 3.0 * 4 * kBuckets, s);
+    hipLaunchKernelGGL(topk_keys_kernel, dim3(blocks), dim3(256), 0, s, score, valid, n, keys, hist,
                        n_valid);
-    int splits = (int)std::min<int64_t>(32, std::max<int64_t>(1, 4096 / blocks));
-    const int chunk = (int)(mrcnn::ceil_div(mrcnn::ceil_div(n, splits), 32) * 32);
-    splits = (int)mrcnn::ceil_div(n, chunk);
-    {
-        mrcnn::ProfScope prof(mrcnn::PROF_TOPK, 0., 12.0 * n, s);
-        hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks, splits), dim3(256), 0, s, keys, n, chunk,
-                           rank);
-    }
-    hipLaunchKernelGGL(topk_scatter_kernel, dim3(blocks), dim3(256), 0, s, keys, rank, n, k, order,
-                       n_valid, n_out);
+    hipLaunchKernelGGL(topk_scan_kernel, dim3(1), dim3(1024), 0, s, hist, start);
+    hipLaunchKernelGGL(topk_place_kernel, dim3(blocks), dim3(256), 0, s, keys, n, hist, start,
+                       sorted);
+    hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks, kRankSplits), dim3(256), 0, s, sorted, start,
+                       n, rank);
+    hipLaunchKernelGGL(topk_scatter_kernel, dim3(blocks), dim3(256), 0, s, sorted, start, rank, n,
+                       k, order, n_valid, n_out);
     return mrcnn::check_launch("topk_desc");
 }
 

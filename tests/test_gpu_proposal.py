@@ -96,6 +96,30 @@ def test_topk_desc_bit_exact(dev, n, k):
     assert np.array_equal(order[:kk].cpu().numpy(), ref.astype(np.int32))
 
 
+@pytest.mark.parametrize('kind', ['all_equal', 'two_values', 'narrow', 'signed_zero_inf'])
+def test_topk_degenerate_score_distributions(dev, kind):
+    """The bucketed rank (top 16 key bits) must stay exact when a bucket holds everything
+    (all scores equal: pure index order) or when scores straddle sign / zero / infinities."""
+    rng = np.random.RandomState(11)
+    n, k = 64260, 12000
+    if kind == 'all_equal':
+        score = np.full(n, 0.25, np.float32)
+    elif kind == 'two_values':
+        score = rng.choice(np.array([-1.5, 3.0], np.float32), n)
+    elif kind == 'narrow':        # one exponent, 7 equal leading mantissa bits: one bucket
+        score = (1.0 + rng.randint(0, 1 << 16, n).astype(np.float32) * 2.0 ** -23).astype(np.float32)
+    else:
+        score = rng.standard_normal(n).astype(np.float32)
+        score[rng.randint(0, n, 500)] = 0.0
+        score[rng.randint(0, n, 500)] = -0.0
+        score[rng.randint(0, n, 50)] = np.inf
+        score[rng.randint(0, n, 50)] = -np.inf
+    order, n_out = P.topk_desc(torch.tensor(score, device=dev), k)
+    ref = np_ref.stable_argsort_desc(score)[:k].astype(np.int32)
+    assert int(n_out.item()) == k
+    assert np.array_equal(order.cpu().numpy()[:k], ref)
+
+
 def test_topk_with_validity(dev):
     rng = np.random.RandomState(12)
     n = 3000
