@@ -82,8 +82,9 @@ SIGNATURES = {
     'mrcnn_softmax': (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp]),
     'mrcnn_sgd_momentum_wd': (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
                                       c_vp]),
-    'mrcnn_prepare_image': (c_int, [c_vp, c_int, c_int, c_int, ctypes.c_double, ctypes.POINTER(c_f32), c_vp,
-                                    c_int, c_int, c_int, c_int, c_int, c_vp]),
+    'mrcnn_prepare_image': (c_int, [c_vp, c_int, c_int, c_int, c_int, ctypes.c_double,
+                                    ctypes.POINTER(c_f32), c_vp, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_vp]),
     'mrcnn_paste_masks': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     'mrcnn_decode_cls_boxes': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_f32,
                                        ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), c_f32,

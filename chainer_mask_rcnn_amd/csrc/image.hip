@@ -29,22 +29,24 @@ __device__ __forceinline__ Lin lin_coord(int d, double scale, int n_in)
     return l;
 }
 
-// src (C,H,W) fp32 -> dst image n of an (N, dstH, dstW, C) NHWC batch, rows/cols beyond
-// (outH, outW) are left untouched (the caller zero-fills the batch).
-__global__ void prepare_kernel(const float *__restrict__ src, int C, int H, int W, double inv_scale,
+// src (C,H,W) fp32 or uint8 -> dst image n of an (N, dstH, dstW, C) NHWC batch, rows/cols
+// beyond (outH, outW) are left untouched (the caller zero-fills the batch).  flip_x writes
+// the resized image mirrored left-right (chainercv random_flip after the resize).
+template <typename T>
+__global__ void prepare_kernel(const T *__restrict__ src, int C, int H, int W, double inv_scale,
                                float m0, float m1, float m2, float *__restrict__ dst, int dstH,
-                               int dstW, int outH, int outW, int n)
+                               int dstW, int outH, int outW, int n, int flip_x)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= outW || y >= outH) return;
     const Lin ly = lin_coord(y, inv_scale, H);
-    const Lin lx = lin_coord(x, inv_scale, W);
+    const Lin lx = lin_coord(flip_x ? outW - 1 - x : x, inv_scale, W);
     float *o = dst + (((int64_t)n * dstH + y) * dstW + x) * C;
     for (int c = 0; c < C; ++c) {
-        const float *p = src + (int64_t)c * H * W;
-        const float top = p[ly.i0 * W + lx.i0] * (1.f - lx.t) + p[ly.i0 * W + lx.i1] * lx.t;
-        const float bot = p[ly.i1 * W + lx.i0] * (1.f - lx.t) + p[ly.i1 * W + lx.i1] * lx.t;
+        const T *p = src + (int64_t)c * H * W;
+        const float top = (float)p[ly.i0 * W + lx.i0] * (1.f - lx.t) + (float)p[ly.i0 * W + lx.i1] * lx.t;
+        const float bot = (float)p[ly.i1 * W + lx.i0] * (1.f - lx.t) + (float)p[ly.i1 * W + lx.i1] * lx.t;
         const float v = top * (1.f - ly.t) + bot * ly.t;
         o[c] = v - (c == 0 ? m0 : (c == 1 ? m1 : m2));
     }
@@ -94,16 +96,23 @@ __global__ void paste_masks_kernel(const float *__restrict__ logits, const int32
 
 }  // namespace
 
-extern "C" int mrcnn_prepare_image(const float *src_chw, int C, int H, int W, double scale,
-                                   const float *mean_host, float *dst_nhwc, int dstH, int dstW,
-                                   int outH, int outW, int n, void *stream)
+extern "C" int mrcnn_prepare_image(const void *src_chw, int src_is_u8, int C, int H, int W,
+                                   double scale, const float *mean_host, float *dst_nhwc, int dstH,
+                                   int dstW, int outH, int outW, int n, int flip_x, void *stream)
 {
     MRCNN_REQUIRE(src_chw && dst_nhwc && mean_host, "prepare_image: null pointer");
     MRCNN_REQUIRE(C == 3 && H > 0 && W > 0 && scale > 0., "prepare_image: expects a 3-channel image");
     MRCNN_REQUIRE(outH <= dstH && outW <= dstW && outH > 0 && outW > 0, "prepare_image: bad sizes");
-    hipLaunchKernelGGL(prepare_kernel, dim3((outW + 255) / 256, outH), dim3(256), 0,
-                       mrcnn::as_stream(stream), src_chw, C, H, W, 1.0 / scale,
-                       mean_host[0], mean_host[1], mean_host[2], dst_nhwc, dstH, dstW, outH, outW, n);
+    if (src_is_u8)
+        hipLaunchKernelGGL(prepare_kernel<uint8_t>, dim3((outW + 255) / 256, outH), dim3(256), 0,
+                           mrcnn::as_stream(stream), (const uint8_t *)src_chw, C, H, W, 1.0 / scale,
+                           mean_host[0], mean_host[1], mean_host[2], dst_nhwc, dstH, dstW, outH,
+                           outW, n, flip_x);
+    else
+        hipLaunchKernelGGL(prepare_kernel<float>, dim3((outW + 255) / 256, outH), dim3(256), 0,
+                           mrcnn::as_stream(stream), (const float *)src_chw, C, H, W, 1.0 / scale,
+                           mean_host[0], mean_host[1], mean_host[2], dst_nhwc, dstH, dstW, outH,
+                           outW, n, flip_x);
     return mrcnn::check_launch("prepare_image");
 }
 

@@ -146,11 +146,13 @@ class MaskRCNN(torch.nn.Module):
         return [roi_masks[roi_indices == i] for i in range(batch_size)]
 
     # ------------------------------------------------------------------ image I/O on device
-    def prepare(self, imgs):
+    def prepare(self, imgs, x_flips=None):
         """models/mask_rcnn.py:152-176 + concat_examples(padding=0): a list of CHW RGB images
         (uint8 or float) -> zero-padded device batch x (N,3,H,W) channels-last, original
         sizes and scales.  The bilinear resize (cv2 INTER_LINEAR rule) and the mean
-        subtraction run in one HIP kernel per image."""
+        subtraction run in one HIP kernel per image; uint8 images are uploaded as they are.
+        ``x_flips`` (extension, used by datasets.MaskRCNNTransform): per-image booleans, mirror
+        the resized image left-right in the same pass."""
         dev = next(self.parameters()).device
         sizes, scales, outs = [], [], []
         for img in imgs:
@@ -168,10 +170,13 @@ class MaskRCNN(torch.nn.Module):
         batch = torch.zeros((N, Hm, Wm, 3), dtype=torch.float32, device=dev)
         mean = (_lib.c_f32 * 3)(*[float(v) for v in np.asarray(self.mean).ravel()])
         for n, img in enumerate(imgs):
-            src = torch.as_tensor(np.ascontiguousarray(img, dtype=np.float32)).to(dev)
-            _lib.call('mrcnn_prepare_image', _lib.ptr(src), 3, sizes[n][0], sizes[n][1],
+            is_u8 = getattr(img, 'dtype', None) == np.uint8
+            host = np.ascontiguousarray(img, dtype=np.uint8 if is_u8 else np.float32)
+            src = torch.as_tensor(host).to(dev)
+            flip = bool(x_flips[n]) if x_flips is not None else False
+            _lib.call('mrcnn_prepare_image', _lib.ptr(src), int(is_u8), 3, sizes[n][0], sizes[n][1],
                       float(scales[n]), mean, _lib.ptr(batch), Hm, Wm, outs[n][0], outs[n][1], n,
-                      _lib.stream_ptr())
+                      int(flip), _lib.stream_ptr())
         return batch.permute(0, 3, 1, 2), sizes, scales
 
     def _to_masks(self, bboxes, labels, scores, roi_masks, sizes):

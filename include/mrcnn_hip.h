@@ -279,11 +279,13 @@ int mrcnn_detect_sort(const float *prob, const float *cls_bbox, int R, int n_cla
 /* ---- Image I/O at both ends of predict (device restatement of the reference's cv2 calls) ---- */
 /* MaskRCNN.prepare (models/mask_rcnn.py:152-176) for one image + its slot in the zero-padded
  * batch (datasets/concat_examples.py:20-26): bilinear resize by `scale` (OpenCV INTER_LINEAR
- * float rule) of src (C=3,H,W) fp32 into image n of dst (N,dstH,dstW,3) NHWC, minus the RGB
- * mean (mean_host: HOST pointer to 3 floats).  (outH,outW) = rounded scaled size. */
-int mrcnn_prepare_image(const float *src_chw, int C, int H, int W, double scale,
+ * float rule) of src (C=3,H,W) — fp32, or uint8 as decoded when src_is_u8 — into image n of
+ * dst (N,dstH,dstW,3) NHWC, minus the RGB mean (mean_host: HOST pointer to 3 floats).
+ * (outH,outW) = rounded scaled size.  flip_x != 0 mirrors the resized image left-right: the
+ * random_flip of datasets/transforms.py:38-40 folded into the same pass. */
+int mrcnn_prepare_image(const void *src_chw, int src_is_u8, int C, int H, int W, double scale,
                         const float *mean_host, float *dst_nhwc, int dstH, int dstW,
-                        int outH, int outW, int n, void *stream);
+                        int outH, int outW, int n, int flip_x, void *stream);
 /* segm_results / expand_boxes (models/mask_rcnn.py:44-107): mask_logits (D,M,M,Kc) NHWC head
  * outputs, label (D) foreground class per detection, bbox (D,4) yx in image coordinates ->
  * out (D,im_h,im_w) uint8 {0,1}: sigmoid, 1-pixel zero pad, box expanded by (M+2)/M and
