@@ -51,11 +51,10 @@ class MaskRCNN(torch.nn.Module):
         return roi_cls_locs, roi_scores, rois, roi_indices, roi_masks
 
     # ------------------------------------------------------------------ inference
-    def _suppress(self, cls_bbox, prob):
-        """Per-class score threshold + NMS (:178-202) for one image, all classes batched.
-
-        cls_bbox (R, n_class, 4), prob (R, n_class) device tensors.  Returns host arrays
-        bbox (D,4) f32, label (D,) i32, score (D,) f32 ordered by class then by score."""
+    def _suppress_queue(self, cls_bbox, prob):
+        """Device half of the per-class score threshold + NMS (:178-202) for one image, all
+        classes batched: queues the kernels and returns the device results without
+        synchronising.  cls_bbox (R, n_class, 4), prob (R, n_class) device tensors."""
         R = cls_bbox.shape[0]
         n_fg = self.n_class - 1
         dev = cls_bbox.device
@@ -69,10 +68,16 @@ class MaskRCNN(torch.nn.Module):
                   R, self.n_class, float(self.score_thresh), _lib.ptr(sorted_boxes),
                   _lib.ptr(sorted_prob), _lib.ptr(counts), _lib.ptr(ws), _lib.stream_ptr())
         keep, n_keep = P.nms_sorted_batched(sorted_boxes, counts, self.nms_thresh)
+        return keep, n_keep, sorted_boxes, sorted_prob
+
+    @staticmethod
+    def _suppress_finish(keep, n_keep, sorted_boxes, sorted_prob):
+        """Host half: gather the kept rows class by class.  Returns host arrays bbox (D,4)
+        f32, label (D,) i32, score (D,) f32 ordered by class then by score."""
         keep, n_keep = keep.cpu().numpy(), n_keep.cpu().numpy()
         sorted_boxes, sorted_prob = sorted_boxes.cpu().numpy(), sorted_prob.cpu().numpy()
         bbox, label, score = [], [], []
-        for l in range(n_fg):
+        for l in range(len(n_keep)):
             k = keep[l, :n_keep[l]]
             bbox.append(sorted_boxes[l, k])
             label.append(np.full((len(k),), l, dtype=np.int32))
@@ -81,6 +86,9 @@ class MaskRCNN(torch.nn.Module):
                 np.concatenate(label, 0).astype(np.int32),
                 np.concatenate(score, 0).astype(np.float32))
 
+    def _suppress(self, cls_bbox, prob):
+        return self._suppress_finish(*self._suppress_queue(cls_bbox, prob))
+
     def _to_bboxes(self, roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales):
         probs = F.softmax(roi_scores.detach())
         roi_cls_locs = roi_cls_locs.detach()
@@ -88,22 +96,29 @@ class MaskRCNN(torch.nn.Module):
             roi_cls_locs = roi_cls_locs.contiguous()
         mean = (_lib.c_f32 * 4)(*self.loc_normalize_mean)
         std = (_lib.c_f32 * 4)(*self.loc_normalize_std)
-        bboxes, labels, scores = [], [], []
+        # RoIs are grouped by image, in order (RegionProposalNetwork): one host read gives the
+        # slice bounds.  The device work of every image is queued first; the host halves run
+        # afterwards while later images' kernels are still executing.
+        counts = np.bincount(roi_indices.cpu().numpy().astype(np.int64), minlength=len(sizes))
+        bounds = np.concatenate([[0], np.cumsum(counts)])
+        queued = []
         for index in range(len(sizes)):
-            scale = float(scales[index])
-            size = sizes[index]
-            keep = (roi_indices == index)
-            roi = rois[keep].contiguous()
-            loc = roi_cls_locs[keep]
-            prob = probs[keep].contiguous()
+            lo, hi = int(bounds[index]), int(bounds[index + 1])
+            roi = rois[lo:hi].contiguous()
+            loc = roi_cls_locs[lo:hi]
+            prob = probs[lo:hi].contiguous()
             R = roi.shape[0]
             cls_bbox = torch.empty((R, self.n_class, 4), dtype=torch.float32, device=roi.device)
             if loc.stride(1) != 1 or loc.stride(0) != loc.shape[1]:
                 loc = loc.contiguous()
             _lib.call('mrcnn_decode_cls_boxes', _lib.ptr(roi), _lib.ptr(loc), loc.stride(0),
-                      _lib.ptr(cls_bbox), R, self.n_class, scale, mean, std,
-                      float(size[0]), float(size[1]), _lib.stream_ptr())
-            bbox, label, score = self._suppress(cls_bbox, prob)
+                      _lib.ptr(cls_bbox), R, self.n_class, float(scales[index]), mean, std,
+                      float(sizes[index][0]), float(sizes[index][1]), _lib.stream_ptr())
+            queued.append(self._suppress_queue(cls_bbox, prob))
+
+        bboxes, labels, scores = [], [], []
+        for q in queued:
+            bbox, label, score = self._suppress_finish(*q)
 
             bbox_int = np.round(bbox).astype(np.int32)
             bbox_sizes = ((bbox_int[:, 2] - bbox_int[:, 0]) * (bbox_int[:, 3] - bbox_int[:, 1]))
@@ -224,10 +239,15 @@ class MaskRCNN(torch.nn.Module):
                     h, x.shape[2:], scales)
                 # one image's proposals at a time: keeps every activation below the 2 GiB
                 # buffer-addressing limit of the conv kernels (8 x 1000 RoIs would not fit)
+                # (rois are grouped by image in order: one host read of the index column gives
+                # the slice bounds; a boolean mask per image would synchronise eight times and
+                # leave the GPU idle while the host queues the next head)
+                counts = np.bincount(roi_indices.cpu().numpy(), minlength=x.shape[0])
+                bounds = np.concatenate([[0], np.cumsum(counts)])
                 locs, scs = [], []
                 for i in range(x.shape[0]):
-                    sel = roi_indices == i
-                    l_i, s_i, _ = self.head(h, rois[sel], roi_indices[sel], pred_mask=False)
+                    lo, hi = int(bounds[i]), int(bounds[i + 1])
+                    l_i, s_i, _ = self.head(h, rois[lo:hi], roi_indices[lo:hi], pred_mask=False)
                     locs.append(l_i)
                     scs.append(s_i)
                 roi_cls_locs = torch.cat(locs, dim=0)

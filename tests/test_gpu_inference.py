@@ -56,9 +56,9 @@ def test_decode_cls_boxes_bit_exact(dev):
     out = torch.empty((R, n_class, 4), device=dev)
     mean = (_lib.c_f32 * 4)(0., 0., 0., 0.)
     std = (_lib.c_f32 * 4)(0.1, 0.1, 0.2, 0.2)
-    _lib.call('mrcnn_decode_cls_boxes', _lib.ptr(torch.tensor(roi, device=dev)),
-              _lib.ptr(torch.tensor(loc, device=dev)), n_class * 4, _lib.ptr(out), R, n_class,
-              1.6, mean, std, 600., 900., _lib.stream_ptr())
+    roi_d, loc_d = torch.tensor(roi, device=dev), torch.tensor(loc, device=dev)   # keep alive
+    _lib.call('mrcnn_decode_cls_boxes', _lib.ptr(roi_d), _lib.ptr(loc_d), n_class * 4,
+              _lib.ptr(out), R, n_class, 1.6, mean, std, 600., 900., _lib.stream_ptr())
     ref = np_infer.decode_cls_boxes(roi, loc, n_class, 1.6, (600, 900)).reshape(R, n_class, 4)
     assert (out.cpu().numpy() != ref).mean() < 1e-6
 
