@@ -406,6 +406,14 @@ def bottleneck(x, conv1, bn1, conv2, bn2, conv3, bn3, conv4=None, bn4=None, stri
 # stages a mask: they all run the plain 168-register kernels, three workgroups per CU.  Only
 # the gradient entering the stage from autograd takes one elementwise masking pass.
 # ---------------------------------------------------------------------------------------
+# Weight gradients of the backbone's small-M layers (<= 40 000 output pixels: res3 / res4) are
+# queued on a second HIP stream: such a launch has only 2-4 workgroups per CU, so the wgrad and
+# the next dgrad share the GPU (same-box A/B: 54.4 -> 54.0 ms per step).  For the large res5
+# launches the same trick measured no overlap (USE_WGRAD_STREAM above).
+SMALL_WGRAD_SIDE_STREAM = True
+SMALL_WGRAD_MAX_PIXELS = 40000
+
+
 class _StageFn(torch.autograd.Function):
 
     @staticmethod
@@ -456,6 +464,11 @@ class _StageFn(torch.autograd.Function):
             xin = y
             pos += n
         gy = nhwc(gy)
+        # small-M layers (backbone stages) leave CUs idle: their weight gradients go to a
+        # second stream so that they can share the GPU with the next dgrad
+        d_top = ctx.blocks[-1][0][2]
+        side = wgrad_stream(gy.device) if (
+            SMALL_WGRAD_SIDE_STREAM and d_top.N * d_top.P * d_top.Q <= SMALL_WGRAD_MAX_PIXELS) else None
         # gm: gradient w.r.t. the block output, already through that output's ReLU
         gm = epilogue_bwd(gy, acts[-1][3], None)
         for i in range(len(acts) - 1, -1, -1):
@@ -467,16 +480,16 @@ class _StageFn(torch.autograd.Function):
             # output ReLU (= this block's input); the stage input belongs to someone else
             xm = None if first else x
             if ng[base + 6]:
-                grads[base + 6] = _wgrad_raw(d3, h2, gm, W3, None, None, row_scale=s3)
+                grads[base + 6] = _wgrad_raw(d3, h2, gm, W3, None, None, side, row_scale=s3)
             if W4 is not None and ng[base + 9]:
-                grads[base + 9] = _wgrad_raw(d4, x, gm, W4, None, None, row_scale=s4)
+                grads[base + 9] = _wgrad_raw(d4, x, gm, W4, None, None, side, row_scale=s4)
             gh2 = _dgrad_raw(d3, gm, nhwc(W3), None, None, fold_scale=s3,
                              out_mask_y=h2, out_scale=s2)
             if ng[base + 3]:
-                grads[base + 3] = _wgrad_raw(d2, h1, gh2, W2, None, None)
+                grads[base + 3] = _wgrad_raw(d2, h1, gh2, W2, None, None, side)
             gh1 = _dgrad_raw(d2, gh2, nhwc(W2), None, None, out_mask_y=h1, out_scale=s1)
             if ng[base]:
-                grads[base] = _wgrad_raw(d1, x, gh1, W1, None, None)
+                grads[base] = _wgrad_raw(d1, x, gh1, W1, None, None, side)
             if first and not ng[0]:
                 break
             if W4 is None:

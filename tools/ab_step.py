@@ -22,6 +22,10 @@ def toggles(name):
         plain = lambda a, dt, dev: torch.tensor(a, dtype=dt, device=dev)
         return (lambda: setattr(mask_rcnn_train_chain, '_upload', orig)), \
                (lambda: setattr(mask_rcnn_train_chain, '_upload', plain))
+    if name == 'wside':
+        import chainer_mask_rcnn_amd.functions.conv as C
+        return (lambda: setattr(C, 'SMALL_WGRAD_SIDE_STREAM', True)), \
+               (lambda: setattr(C, 'SMALL_WGRAD_SIDE_STREAM', False))
     raise SystemExit('unknown toggle ' + name)
 
 
