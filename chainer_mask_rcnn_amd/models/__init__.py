@@ -1,10 +1,18 @@
-# flake8: noqa
-"""Same public names as /root/reference/chainer_mask_rcnn/models/__init__.py:1-9."""
-from . import utils
+"""Model classes of the hot path; the public names are those of the reference's
+``chainer_mask_rcnn.models`` package."""
+from . import utils  # noqa: F401
+from . import mask_rcnn as _m
+from . import mask_rcnn_resnet as _mr
+from . import mask_rcnn_train_chain as _tc
+from . import region_proposal_network as _rpn
+from . import resnet_extractor as _re
 
-from .mask_rcnn import MaskRCNN
-from .mask_rcnn_resnet import MaskRCNNResNet
-from .mask_rcnn_train_chain import MaskRCNNTrainChain
-from .region_proposal_network import RegionProposalNetwork
-from .resnet_extractor import ResNet101Extractor
-from .resnet_extractor import ResNet50Extractor
+MaskRCNN = _m.MaskRCNN
+MaskRCNNResNet = _mr.MaskRCNNResNet
+MaskRCNNTrainChain = _tc.MaskRCNNTrainChain
+RegionProposalNetwork = _rpn.RegionProposalNetwork
+ResNet50Extractor = _re.ResNet50Extractor
+ResNet101Extractor = _re.ResNet101Extractor
+
+__all__ = ['MaskRCNN', 'MaskRCNNResNet', 'MaskRCNNTrainChain', 'RegionProposalNetwork',
+           'ResNet50Extractor', 'ResNet101Extractor', 'utils']
