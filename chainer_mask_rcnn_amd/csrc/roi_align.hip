@@ -292,6 +292,175 @@ roi_align_bwd_gather_kernel(const V *__restrict__ gy, const float *__restrict__ 
     }
 }
 
+// ---- pixel-owner backward (no atomics, deterministic) -------------------------------------
+// The gather form above still issues one atomic per (RoI patch pixel, channel): ~1.7e8 float
+// atomics at the C2 shape, which bound it at 1.35 ms.  Here every feature-map pixel is OWNED
+// by one workgroup, which sums the contributions of all RoIs that cover it in registers and
+// stores the result once (no atomics, no zero-fill, summation order = RoI order: bit-
+// reproducible run to run):
+//   roi_rows_kernel      (grid H x N)            per (image, row): the ordered list of RoIs
+//                                                whose patch contains the row
+//   roi_align_bwd_rows   (grid W/XT x H x N)     XT pixels of one row x all channels; RoIs of
+//                                                the row's list are processed four at a time:
+//                                                their separable weights Ay[ph], Bx[pw][x] are
+//                                                built cooperatively in LDS, then each lane
+//                                                (one float4 of channels) streams the
+//                                                contributing gy bins with coalesced reads.
+struct RoiExtent { int ylo, yhi, xlo, xhi; };
+
+__device__ __forceinline__ RoiExtent roi_extent(const RoiGeom &g, int H, int W, int PH, int PW)
+{
+    const float y_first = g.start_h + .5f * g.bin_h / (float)g.grid_h;
+    const float y_last = g.start_h + (PH - 1) * g.bin_h + (g.grid_h - .5f) * g.bin_h / (float)g.grid_h;
+    const float x_first = g.start_w + .5f * g.bin_w / (float)g.grid_w;
+    const float x_last = g.start_w + (PW - 1) * g.bin_w + (g.grid_w - .5f) * g.bin_w / (float)g.grid_w;
+    RoiExtent e;
+    e.ylo = max(0, min(H - 1, (int)floorf(fmaxf(y_first, 0.f)) - 1));
+    e.yhi = max(0, min(H - 1, (int)floorf(fmaxf(y_last, 0.f)) + 2));
+    e.xlo = max(0, min(W - 1, (int)floorf(fmaxf(x_first, 0.f)) - 1));
+    e.xhi = max(0, min(W - 1, (int)floorf(fmaxf(x_last, 0.f)) + 2));
+    return e;
+}
+
+// list[(n*H + y)*R + k] = k-th RoI (ascending index) of image n whose patch contains row y
+__global__ void __launch_bounds__(256)
+roi_rows_kernel(const float *__restrict__ rois, int R, int H, int W, int PH, int PW,
+                float spatial_scale, int sampling_ratio, uint16_t *__restrict__ lists,
+                int32_t *__restrict__ counts)
+{
+    __shared__ int wave_cnt[4];
+    const int y = blockIdx.x, n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint16_t *__restrict__ list = lists + ((int64_t)n * H + y) * R;
+    int base = 0;
+    for (int r0 = 0; r0 < R; r0 += 256) {
+        const int r = r0 + tid;
+        bool in = false;
+        if (r < R) {
+            const RoiGeom g = roi_geom(rois + 5 * r, spatial_scale, PH, PW, sampling_ratio);
+            if (g.batch == n) {
+                const RoiExtent e = roi_extent(g, H, W, PH, PW);
+                in = y >= e.ylo && y <= e.yhi;
+            }
+        }
+        const unsigned long long b = __ballot(in);
+        if (lane == 0) wave_cnt[wave] = (int)__popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (in) list[off + (int)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)r;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) counts[n * H + y] = base;
+}
+
+constexpr int kRowsXT = 8;      // pixels of a row per workgroup
+constexpr int kRowsGroup = 4;   // RoIs whose weights are built per barrier pair
+constexpr int kRowsMaxBins = 16;
+
+template <typename V>
+__global__ void __launch_bounds__(256)
+roi_align_bwd_rows_kernel(const V *__restrict__ gy, const float *__restrict__ rois,
+                          const uint16_t *__restrict__ lists, const int32_t *__restrict__ counts,
+                          V *__restrict__ gx, int R, int H, int W, int CV, int PH, int PW,
+                          float spatial_scale, int sampling_ratio, int OH, int OW, int BS)
+{
+    constexpr int XT = kRowsXT, GR = kRowsGroup, MB = kRowsMaxBins;
+    __shared__ __attribute__((aligned(16))) float sBx[GR][MB][XT];   // [roi][pw][x]
+    __shared__ float sAy[GR][MB];                                     // already / count
+    __shared__ int sRoi[GR];                                          // RoI index or -1 (skip)
+    const int x0 = blockIdx.x * XT, y = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int cnt = counts[n * H + y];
+    const uint16_t *__restrict__ list = lists + ((int64_t)n * H + y) * R;
+    const int per_roi = OH + OW * XT;            // weight entries of one RoI
+    const int nthreads = blockDim.x;
+
+    for (int c0 = 0; c0 < CV; c0 += nthreads) {
+        const int c = c0 + tid;
+        V acc[XT];
+#pragma unroll
+        for (int x = 0; x < XT; ++x) acc[x] = VecOps<V>::zero();
+
+        for (int k0 = 0; k0 < cnt; k0 += GR) {
+            __syncthreads();                     // the previous group's weights are consumed
+            for (int e = tid; e < GR * per_roi; e += nthreads) {
+                const int gi = e / per_roi, j = e - gi * per_roi;
+                const int k = k0 + gi;
+                if (k >= cnt) {
+                    if (j == 0) sRoi[gi] = -1;
+                    continue;
+                }
+                const int r = list[k];
+                const RoiGeom g = roi_geom(rois + 5 * r, spatial_scale, PH, PW, sampling_ratio);
+                if (j == 0) {
+                    const RoiExtent ex = roi_extent(g, H, W, PH, PW);
+                    sRoi[gi] = (ex.xhi < x0 || ex.xlo > x0 + XT - 1) ? -1 : r;
+                }
+                if (j < OH) {
+                    const int ph = j * BS;
+                    float a = 0.f;
+                    for (int iy = 0; iy < g.grid_h; ++iy) {
+                        const float yy = g.start_h + ph * g.bin_h +
+                                         (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
+                        const Tap1D t = tap1d(yy, H);
+                        if (!t.valid) continue;
+                        if (t.lo == y) a += t.h;
+                        if (t.hi == y) a += t.l;
+                    }
+                    sAy[gi][j] = a / g.count;
+                } else {
+                    const int q = j - OH, ow_ = q / XT, xi = q - ow_ * XT;
+                    const int pw = ow_ * BS, x = x0 + xi;
+                    float b = 0.f;
+                    for (int ix = 0; ix < g.grid_w; ++ix) {
+                        const float xx = g.start_w + pw * g.bin_w +
+                                         (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
+                        const Tap1D t = tap1d(xx, W);
+                        if (!t.valid) continue;
+                        if (t.lo == x) b += t.h;
+                        if (t.hi == x) b += t.l;
+                    }
+                    sBx[gi][ow_][xi] = b;
+                }
+            }
+            __syncthreads();
+            if (c < CV) {
+                for (int gi = 0; gi < GR; ++gi) {
+                    const int r = sRoi[gi];
+                    if (r < 0) continue;
+                    const V *__restrict__ top = gy + (int64_t)r * OH * OW * CV + c;
+                    for (int oh = 0; oh < OH; ++oh) {
+                        const float ay = sAy[gi][oh];
+                        if (ay == 0.f) continue;
+                        for (int ow_ = 0; ow_ < OW; ++ow_) {
+                            float w[XT];
+                            bool any = false;
+#pragma unroll
+                            for (int x = 0; x < XT; ++x) {
+                                w[x] = sBx[gi][ow_][x];
+                                any |= w[x] != 0.f;
+                            }
+                            if (!any) continue;
+                            const V v = top[(int64_t)(oh * OW + ow_) * CV];
+#pragma unroll
+                            for (int x = 0; x < XT; ++x)
+                                if (w[x] != 0.f) acc[x] = vfma(acc[x], ay * w[x], v);
+                        }
+                    }
+                }
+            }
+        }
+        if (c < CV) {
+            V *__restrict__ row = gx + (((int64_t)n * H + y) * W + x0) * CV + c;
+#pragma unroll
+            for (int x = 0; x < XT; ++x)
+                if (x0 + x < W) row[(int64_t)x * CV] = acc[x];
+        }
+    }
+}
+
 inline int pick_threads(int cv)
 {
     int t = ((cv + 63) / 64) * 64;
@@ -346,22 +515,52 @@ extern "C" int mrcnn_roi_align_fwd(const float *x, const float *rois, float *y, 
                                   sampling_ratio, stream);
 }
 
+extern "C" int64_t mrcnn_roi_align_bwd_workspace_bytes(int N, int H, int R)
+{
+    if (N <= 0 || H <= 0 || R < 0) return 0;
+    // per (image, row): RoI list (uint16) + count (int32), 64-byte aligned sections
+    const int64_t lists = (((int64_t)N * H * R * 2 + 63) / 64) * 64;
+    return lists + (int64_t)N * H * 4 + 64;
+}
+
 extern "C" int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float *gx, int N, int H,
                                       int W, int C, int R, int PH, int PW, int bin_stride,
-                                      float spatial_scale, int sampling_ratio, void *stream)
+                                      float spatial_scale, int sampling_ratio, void *ws,
+                                      void *stream)
 {
     if (int rc = check_args(gy, rois, gx, N, H, W, C, R, PH, PW, sampling_ratio)) return rc;
     MRCNN_REQUIRE(bin_stride >= 1, "roi_align: bin_stride must be >= 1");
     hipStream_t s = mrcnn::as_stream(stream);
     MRCNN_REQUIRE(gx != nullptr, "roi_align_bwd: null gx");
-    MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * H * W * C, s));
-    if (R == 0) return 0;
     const int OH = (PH + bin_stride - 1) / bin_stride, OW = (PW + bin_stride - 1) / bin_stride;
     const int bins = R * OH * OW;
+    const bool vec = C % 4 == 0 && ((uintptr_t)gx % 16 == 0) && ((uintptr_t)gy % 16 == 0);
+    if (ws && R > 0 && R <= 65535 && H <= 65535 && N <= 65535 && OH <= kRowsMaxBins &&
+        OW <= kRowsMaxBins) {
+        // pixel-owner form: every gx element is written exactly once, no zero-fill.
+        // algorithmic bytes: read R*OH*OW*C, write the feature-map gradient
+        mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_BWD, 0.,
+                              4.0 * ((double)bins * C + (double)N * H * W * C), s);
+        uint16_t *lists = (uint16_t *)ws;
+        int32_t *counts = (int32_t *)((char *)ws + (((int64_t)N * H * R * 2 + 63) / 64) * 64);
+        hipLaunchKernelGGL(roi_rows_kernel, dim3(H, N), dim3(256), 0, s, rois, R, H, W, PH, PW,
+                           spatial_scale, sampling_ratio, lists, counts);
+        const dim3 grid((W + kRowsXT - 1) / kRowsXT, H, N);
+        if (vec)
+            hipLaunchKernelGGL(roi_align_bwd_rows_kernel<float4>, grid, dim3(pick_threads(C / 4)), 0,
+                               s, (const float4 *)gy, rois, lists, counts, (float4 *)gx, R, H, W,
+                               C / 4, PH, PW, spatial_scale, sampling_ratio, OH, OW, bin_stride);
+        else
+            hipLaunchKernelGGL(roi_align_bwd_rows_kernel<float>, grid, dim3(pick_threads(C)), 0, s,
+                               gy, rois, lists, counts, gx, R, H, W, C, PH, PW, spatial_scale,
+                               sampling_ratio, OH, OW, bin_stride);
+        return mrcnn::check_launch("roi_align_bwd");
+    }
+    MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * H * W * C, s));
+    if (R == 0) return 0;
     // algorithmic bytes: read R*OH*OW*C, read-modify-write the feature-map gradient
     mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_BWD, 0.,
                           4.0 * ((double)bins * C + 2.0 * (double)N * H * W * C), s);
-    const bool vec = C % 4 == 0 && ((uintptr_t)gx % 16 == 0) && ((uintptr_t)gy % 16 == 0);
     const size_t lds = sizeof(float) * ((size_t)PH + (size_t)(W + 4) * PW) + sizeof(int) * 2 * (W + 4);
     if (lds <= 48 * 1024 && H <= 65535 && R <= 65535) {
         // gather form: one workgroup per (roi, feature row), one atomic per (pixel, channel)
@@ -391,5 +590,5 @@ extern "C" int mrcnn_roi_align_bwd(const float *gy, const float *rois, float *gx
                                    int sampling_ratio, void *stream)
 {
     return mrcnn_roi_align_bwd_ex(gy, rois, gx, N, H, W, C, R, PH, PW, 1, spatial_scale,
-                                  sampling_ratio, stream);
+                                  sampling_ratio, nullptr, stream);
 }

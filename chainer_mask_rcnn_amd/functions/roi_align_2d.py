@@ -12,6 +12,10 @@ from .. import _lib
 from ._layout import nhwc, empty_nhwc
 
 
+# Pixel-owner backward (no atomics, fixed summation order); False = atomic gather form.
+DETERMINISTIC_BACKWARD = True
+
+
 class _ROIAlign2DFn(torch.autograd.Function):
 
     @staticmethod
@@ -40,9 +44,12 @@ class _ROIAlign2DFn(torch.autograd.Function):
         outh, outw, spatial_scale, sampling_ratio, bin_stride = ctx.args
         gy = nhwc(gy)
         gx = empty_nhwc((N, C, H, W), gy.device)
+        R = rois.shape[0]
+        ws = _lib.workspace(_lib.load().mrcnn_roi_align_bwd_workspace_bytes(N, H, R), gy.device,
+                            'roi_align_bwd') if DETERMINISTIC_BACKWARD else None
         _lib.call('mrcnn_roi_align_bwd_ex', _lib.ptr(gy), _lib.ptr(rois), _lib.ptr(gx),
-                  N, H, W, C, rois.shape[0], outh, outw, bin_stride, spatial_scale,
-                  sampling_ratio, _lib.stream_ptr())
+                  N, H, W, C, R, outh, outw, bin_stride, spatial_scale,
+                  sampling_ratio, _lib.ptr(ws), _lib.stream_ptr())
         # no gradient w.r.t. rois (roi_align_2d.py:389, :524)
         return gx, None, None, None, None, None, None
 

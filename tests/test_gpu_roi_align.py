@@ -115,3 +115,41 @@ def test_bin_stride_equals_subsampled_full(dev, C):
     gy_full[:, :, ::2, ::2] = gy
     gx_ref = oracle.roi_align_bwd(gy_full, rois, x.shape, 1 / 16., 0)
     np.testing.assert_allclose(xt.grad.cpu().numpy(), gx_ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('C,outhw,bs', [(8, (14, 14), 1), (260, (7, 5), 1), (64, (14, 14), 2), (6, (3, 16), 1)])
+def test_backward_forms_agree_and_owner_form_is_reproducible(dev, C, outhw, bs):
+    """The pixel-owner backward (ordered RoI lists, no atomics) vs the atomic gather form and
+    vs the oracle; two runs of the owner form are bit-identical (fixed summation order)."""
+    import importlib
+    mod = importlib.import_module('chainer_mask_rcnn_amd.functions.roi_align_2d')
+    rng = np.random.RandomState(C)
+    N, H, W, R = 3, 25, 38, 300
+    y1 = rng.uniform(0, H * 16, R); x1 = rng.uniform(0, W * 16, R)
+    y2 = np.minimum(y1 + rng.uniform(0, 300, R), H * 16); x2 = np.minimum(x1 + rng.uniform(0, 400, R), W * 16)
+    rois = np.stack([rng.randint(0, N, R), x1, y1, x2, y2], 1).astype(np.float32)
+    rois[:5, 3:] = rois[:5, 1:3] + 0.3          # sub-pixel RoIs
+    rois[5] = [1, 0, 0, W * 16, H * 16]         # whole image
+    oh, ow = -(-outhw[0] // bs), -(-outhw[1] // bs)
+    gy = rng.standard_normal((R, C, oh, ow)).astype(np.float32)
+    x = torch.zeros((N, C, H, W), device=dev)
+
+    def run(deterministic):
+        old = mod.DETERMINISTIC_BACKWARD
+        mod.DETERMINISTIC_BACKWARD = deterministic
+        try:
+            xt = x.clone().requires_grad_(True)
+            y = F.roi_align_2d(xt, torch.tensor(rois, device=dev), outhw[0], outhw[1], 1 / 16.,
+                               bin_stride=bs)
+            y.backward(torch.tensor(gy, device=dev))
+            return xt.grad.clone()
+        finally:
+            mod.DETERMINISTIC_BACKWARD = old
+
+    a, b, c = run(True), run(True), run(False)
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    gy_full = np.zeros((R, C) + tuple(outhw), np.float32)
+    gy_full[:, :, ::bs, ::bs] = gy
+    gx_ref = oracle.roi_align_bwd(gy_full, rois, (N, C, H, W), 1 / 16., 0)
+    np.testing.assert_allclose(a.cpu().numpy(), gx_ref, rtol=1e-4, atol=1e-4)
