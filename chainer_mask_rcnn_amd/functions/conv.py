@@ -257,21 +257,30 @@ def _fwd_raw(x, Wc, d, scale, shift, residual, relu):
 USE_TRANSPOSED_DGRAD = True
 
 
+def _flip_transpose(Wc, d, row_scale, out):
+    _lib.call('mrcnn_filter_flip_transpose', _lib.ptr(Wc), _lib.ptr(out), d.K, d.R, d.S, d.C,
+              _lib.ptr(row_scale), _lib.stream_ptr())
+    return out
+
+
+def _uses_transposed_dgrad(d):
+    return USE_TRANSPOSED_DGRAD and d.stride == 1 and d.R == d.S
+
+
 def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, accum=False,
-               out_mask_y=None, out_scale=None, fold_scale=None):
+               out_mask_y=None, out_scale=None, fold_scale=None, wT=None):
     """gx = dgrad(g') with the fused pieces of include/mrcnn_hip.h "Extended backward entry
     points": consumer-side ``mask_y`` / ``in_scale``, producer-side ``out_mask_y`` /
     ``out_scale``, shortcut gradient ``res_g`` (masked by ``res_y`` if given).  ``fold_scale``
     is a per-output-channel scale of the incoming gradient folded into the filter (stride 1)
     or, for the strided kernel, passed as ``in_scale``."""
     gx = out if out is not None else empty_nhwc((d.N, d.C, d.H, d.W), g.device)
-    if USE_TRANSPOSED_DGRAD and d.stride == 1 and d.R == d.S:
-        # forward-form dgrad on the flipped, transposed filter (rebuilt per call: it moves
-        # 2 x the filter bytes, microseconds next to the GEMM)
-        nbytes = 4 * d.K * d.R * d.S * d.C
-        wT = _lib.workspace(nbytes, g.device, 'wT')
-        _lib.call('mrcnn_filter_flip_transpose', _lib.ptr(Wc), _lib.ptr(wT), d.K, d.R, d.S, d.C,
-                  _lib.ptr(fold_scale), _lib.stream_ptr())
+    if _uses_transposed_dgrad(d):
+        # forward-form dgrad on the flipped, transposed filter; ``wT`` = already built (with
+        # fold_scale applied), else rebuilt here (it moves 2 x the filter bytes)
+        if wT is None:
+            wT = _flip_transpose(Wc, d, fold_scale,
+                                 _lib.workspace(4 * d.K * d.R * d.S * d.C, g.device, 'wT'))
         _lib.call('mrcnn_conv2d_dgrad_wt', ctx_desc(d), _lib.ptr(g), _lib.ptr(wT), _lib.ptr(gx),
                   EPI_ACCUM if accum else 0, _lib.ptr(mask_y), _lib.ptr(in_scale),
                   _lib.ptr(res_g), _lib.ptr(res_y), _lib.ptr(out_mask_y), _lib.ptr(out_scale),
@@ -412,6 +421,10 @@ def bottleneck(x, conv1, bn1, conv2, bn2, conv3, bn3, conv4=None, bn4=None, stri
 # launches the same trick measured no overlap (USE_WGRAD_STREAM above).
 SMALL_WGRAD_SIDE_STREAM = True
 SMALL_WGRAD_MAX_PIXELS = 40000
+# Build the transposed filters of a stage during its forward, on the side stream (see _StageFn).
+# Measured (same-box A/B): 53.2 vs 53.0 ms per step — the 42 five-microsecond transposes cost
+# as much next to the forward GEMMs as between the backward ones; off by default.
+PRETRANSPOSE_FILTERS = False
 
 
 class _StageFn(torch.autograd.Function):
@@ -447,6 +460,29 @@ class _StageFn(torch.autograd.Function):
         ctx.blocks = blocks
         ctx.proj = tuple(proj)
         ctx.save_for_backward(*saved)
+        ctx.wT = None
+        if PRETRANSPOSE_FILTERS and any(ctx.needs_input_grad):
+            # The backward's forward-form dgrads need every filter flipped and transposed
+            # (conv3 / conv4 with their affine scale folded in).  The weights are final for
+            # this step, so the ~40 tiny transposes run now on the side stream, next to the
+            # forward GEMMs, instead of between the backward GEMMs.
+            dev = x.device
+            side, main = wgrad_stream(dev), torch.cuda.current_stream(dev)
+            side.wait_stream(main)          # the previous step's SGD update of the weights
+            ctx.wT = []
+            with torch.cuda.stream(side):
+                for (d1, d2, d3, d4), (W1, W2, W3, W4), p0 in blocks:
+                    s3 = params[p0 + 7]
+                    s4 = params[p0 + 10] if W4 is not None else None
+                    t = {}
+                    for key, W, d, sc in (('1', W1, d1, None), ('2', W2, d2, None),
+                                          ('3', W3, d3, s3), ('4', W4, d4, s4)):
+                        if W is not None and _uses_transposed_dgrad(d):
+                            t[key] = _flip_transpose(
+                                nhwc(W), d, sc, torch.empty((W.numel(),), dtype=torch.float32, device=dev))
+                    ctx.wT.append(t)
+                ctx.wT_ready = torch.cuda.Event()
+                ctx.wT_ready.record(side)
         return h
 
     @staticmethod
@@ -469,11 +505,18 @@ class _StageFn(torch.autograd.Function):
         d_top = ctx.blocks[-1][0][2]
         side = wgrad_stream(gy.device) if (
             SMALL_WGRAD_SIDE_STREAM and d_top.N * d_top.P * d_top.Q <= SMALL_WGRAD_MAX_PIXELS) else None
+        if ctx.wT is not None:
+            main = torch.cuda.current_stream(gy.device)
+            main.wait_event(ctx.wT_ready)
+            for t in ctx.wT:
+                for buf in t.values():
+                    buf.record_stream(main)
         # gm: gradient w.r.t. the block output, already through that output's ReLU
         gm = epilogue_bwd(gy, acts[-1][3], None)
         for i in range(len(acts) - 1, -1, -1):
             x, h1, h2, y, s1, s2, s3, s4 = acts[i]
             (d1, d2, d3, d4), (W1, W2, W3, W4), p0 = ctx.blocks[i]
+            wT = ctx.wT[i] if ctx.wT is not None else {}
             base = 3 + p0                      # index of W1 among the forward inputs
             first = i == 0
             # what the gradient leaving this block must be masked with: the previous block's
@@ -484,20 +527,22 @@ class _StageFn(torch.autograd.Function):
             if W4 is not None and ng[base + 9]:
                 grads[base + 9] = _wgrad_raw(d4, x, gm, W4, None, None, side, row_scale=s4)
             gh2 = _dgrad_raw(d3, gm, nhwc(W3), None, None, fold_scale=s3,
-                             out_mask_y=h2, out_scale=s2)
+                             out_mask_y=h2, out_scale=s2, wT=wT.get('3'))
             if ng[base + 3]:
                 grads[base + 3] = _wgrad_raw(d2, h1, gh2, W2, None, None, side)
-            gh1 = _dgrad_raw(d2, gh2, nhwc(W2), None, None, out_mask_y=h1, out_scale=s1)
+            gh1 = _dgrad_raw(d2, gh2, nhwc(W2), None, None, out_mask_y=h1, out_scale=s1,
+                             wT=wT.get('2'))
             if ng[base]:
                 grads[base] = _wgrad_raw(d1, x, gh1, W1, None, None, side)
             if first and not ng[0]:
                 break
             if W4 is None:
-                gm = _dgrad_raw(d1, gh1, nhwc(W1), None, None, res_g=gm, out_mask_y=xm)
+                gm = _dgrad_raw(d1, gh1, nhwc(W1), None, None, res_g=gm, out_mask_y=xm,
+                                wT=wT.get('1'))
             elif d1.stride == 1:
-                gx = _dgrad_raw(d1, gh1, nhwc(W1), None, None)
+                gx = _dgrad_raw(d1, gh1, nhwc(W1), None, None, wT=wT.get('1'))
                 gm = _dgrad_raw(d4, gm, nhwc(W4), None, None, fold_scale=s4, out=gx, accum=True,
-                                out_mask_y=xm)
+                                out_mask_y=xm, wT=wT.get('4'))
             else:
                 gx = _dgrad_raw(d1, gh1, nhwc(W1), None, None)
                 gm = _dgrad_raw(d4, gm, nhwc(W4), None, None, fold_scale=s4, out=gx, accum=True)

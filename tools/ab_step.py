@@ -26,6 +26,10 @@ def toggles(name):
         import chainer_mask_rcnn_amd.functions.conv as C
         return (lambda: setattr(C, 'SMALL_WGRAD_SIDE_STREAM', True)), \
                (lambda: setattr(C, 'SMALL_WGRAD_SIDE_STREAM', False))
+    if name == 'pretranspose':
+        import chainer_mask_rcnn_amd.functions.conv as C
+        return (lambda: setattr(C, 'PRETRANSPOSE_FILTERS', True)), \
+               (lambda: setattr(C, 'PRETRANSPOSE_FILTERS', False))
     raise SystemExit('unknown toggle ' + name)
 
 
