@@ -4,7 +4,9 @@ Runs only in the build container (needs /root/reference).  The reference's
 `chainer_mask_rcnn/functions/roi_align_2d.py` and `affine_channel_2d.py` are
 loaded with importlib under a stand-in `chainer` namespace (chainer itself is
 not installable here; recipe: SURVEY.md Appendix D) and their CPU methods are
-called directly.  Only inputs and outputs (data) are stored.
+called directly; `_enumerate_shifted_anchor` (models/region_proposal_network.py:148-167)
+and `expand_boxes` (models/mask_rcnn.py:44-60) are pure NumPy and are executed from their
+own definitions.  Only inputs and outputs (data) are stored.
 
     python oracle/gen_golden.py
 """
@@ -127,6 +129,36 @@ def main():
     gx, gW, gb = fn.backward((x, Wt, bt), (gy,))
     np.savez(os.path.join(OUT, 'affine_channel_2d.npz'),
              x=x, W=Wt, b=bt, gy=gy, y=y, gx=gx, gW=gW, gb=gb)
+    # (5) the two pure-NumPy helpers of the model files that can be executed without chainer /
+    #     chainercv / cv2: their function definitions are compiled straight out of the
+    #     reference sources (the modules themselves do not import here) and run on seeded
+    #     inputs.  Only inputs and outputs are stored.
+    import ast
+
+    def ref_function(path, name, namespace):
+        tree = ast.parse(open(path).read())
+        node = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name][0]
+        code = compile(ast.Module(body=[node], type_ignores=[]), path, 'exec')
+        exec(code, namespace)
+        return namespace[name]
+
+    models = os.path.join(os.path.dirname(REF), 'models')
+    enum = ref_function(os.path.join(models, 'region_proposal_network.py'),
+                        '_enumerate_shifted_anchor',
+                        {'np': np, 'cuda': types.SimpleNamespace(get_array_module=lambda *a: np)})
+    expand = ref_function(os.path.join(models, 'mask_rcnn.py'), 'expand_boxes',
+                          {'np': np, 'division': None})
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from oracle import np_ref
+    base = np_ref.generate_anchor_base(16, (0.5, 1, 2), (2, 4, 8, 16, 32))   # input data
+    np.savez_compressed(os.path.join(OUT, 'shifted_anchor.npz'), anchor_base=base, feat_stride=16,
+             hw=np.array([[51, 84], [65, 65], [3, 5]]),
+             a0=enum(base, 16, 51, 84), a1=enum(base, 16, 65, 65), a2=enum(base, 16, 3, 5))
+    boxes = (rng.uniform(0, 900, (64, 4))).astype(np.float32)
+    boxes[:, 2:] += boxes[:, :2]
+    boxes[0] = [3.2, 4.7, 3.9, 5.1]
+    np.savez(os.path.join(OUT, 'expand_boxes.npz'), boxes=boxes, scale=16. / 14.,
+             out=expand(boxes.copy(), 16. / 14.))
     print('golden vectors written to', os.path.normpath(OUT))
 
 

@@ -121,3 +121,23 @@ def test_resize_bilinear_identity_and_constant():
     np.testing.assert_allclose(np_ref.resize_bilinear(const, 14, 14), 3.5)
     up = np_ref.resize_bilinear(np.array([[0., 1.]], np.float32), 1, 4)
     np.testing.assert_allclose(up, [[0., 0.25, 0.75, 1.]])
+
+
+def test_shifted_anchor_and_expand_boxes_pinned_to_reference(golden_dir):
+    """Golden vectors produced by the reference's own `_enumerate_shifted_anchor`
+    (models/region_proposal_network.py:148-167) and `expand_boxes` (models/mask_rcnn.py:44-60):
+    the oracle and the product's host helper reproduce them exactly."""
+    import os
+    from chainer_mask_rcnn_amd.utils import bbox as pb
+    from oracle import np_infer
+    d = np.load(os.path.join(golden_dir, 'shifted_anchor.npz'))
+    base, stride = d['anchor_base'], int(d['feat_stride'])
+    assert np.array_equal(pb.generate_anchor_base(16, (0.5, 1, 2), (2, 4, 8, 16, 32)), base)
+    for k, (h, w) in enumerate(d['hw']):
+        ref = d['a%d' % k]
+        assert ref.dtype == np.float32 and ref.shape == (h * w * len(base), 4)
+        assert np.array_equal(np_ref.enumerate_shifted_anchor(base, stride, int(h), int(w)), ref)
+        assert np.array_equal(pb.enumerate_shifted_anchor(base, stride, int(h), int(w)), ref)
+    e = np.load(os.path.join(golden_dir, 'expand_boxes.npz'))
+    out = np_infer.expand_boxes(e['boxes'], float(e['scale']))
+    assert out.dtype == e['out'].dtype and np.array_equal(out, e['out'])
