@@ -88,8 +88,8 @@ SIGNATURES = {
                                     c_int, c_vp]),
     'mrcnn_paste_masks': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     'mrcnn_decode_cls_boxes': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_f32,
-                                       ctypes.POINTER(c_f32), ctypes.POINTER(c_f32), c_f32,
-                                       c_f32, c_vp]),
+                                       ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ctypes.c_double), c_f32, c_f32, c_vp]),
 }
 
 _lib = None

@@ -163,10 +163,12 @@ __global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t 
     dst[e] = r < n ? src[(int64_t)idx[r] * cols + c] : 0.f;
 }
 
+struct Norm4 { double v[4]; };
+
 __global__ void decode_cls_boxes_kernel(const float4 *__restrict__ roi,
                                         const float *__restrict__ cls_loc, int ld_loc,
                                         float4 *__restrict__ cls_bbox, int R, int n_class,
-                                        float inv_scale, float4 mean, float4 stdv, float size_h,
+                                        float inv_scale, Norm4 mean, Norm4 stdv, float size_h,
                                         float size_w, int use_div, float scale)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,9 +179,12 @@ __global__ void decode_cls_boxes_kernel(const float4 *__restrict__ roi,
     if (use_div) { a.x = a.x / scale; a.y = a.y / scale; a.z = a.z / scale; a.w = a.w / scale; }
     else { a.x *= inv_scale; a.y *= inv_scale; a.z *= inv_scale; a.w *= inv_scale; }
     const float *lp = cls_loc + (int64_t)r * ld_loc + 4 * l;
-    // roi_cls_loc * std + mean (:225-229)
-    const float dy = lp[0] * stdv.x + mean.x, dx = lp[1] * stdv.y + mean.y;
-    const float dh = lp[2] * stdv.z + mean.z, dw = lp[3] * stdv.w + mean.w;
+    // (roi_cls_loc * std + mean).astype(float32) (:225-229): mean / std come from Python tuples,
+    // i.e. float64 arrays — the product and sum are formed in double and rounded once
+    const float dy = (float)((double)lp[0] * stdv.v[0] + mean.v[0]);
+    const float dx = (float)((double)lp[1] * stdv.v[1] + mean.v[1]);
+    const float dh = (float)((double)lp[2] * stdv.v[2] + mean.v[2]);
+    const float dw = (float)((double)lp[3] * stdv.v[3] + mean.v[3]);
     const float h = a.z - a.x, w = a.w - a.y;
     const float cy = a.x + 0.5f * h, cx = a.y + 0.5f * w;
     const float ncy = dy * h + cy, ncx = dx * w + cx;
@@ -328,14 +333,14 @@ extern "C" int mrcnn_gather_rows(const float *src, const int32_t *idx, const int
 
 extern "C" int mrcnn_decode_cls_boxes(const float *roi, const float *cls_loc, int ld_loc,
                                       float *cls_bbox, int R, int n_class, float scale,
-                                      const float *mean4, const float *std4, float size_h,
+                                      const double *mean4, const double *std4, float size_h,
                                       float size_w, void *stream)
 {
     MRCNN_REQUIRE(R >= 0 && n_class > 0, "decode_cls_boxes: bad shape");
     if (R == 0) return 0;
     MRCNN_REQUIRE(roi && cls_loc && cls_bbox && mean4 && std4, "decode_cls_boxes: null pointer");
-    const float4 mean = make_float4(mean4[0], mean4[1], mean4[2], mean4[3]);
-    const float4 stdv = make_float4(std4[0], std4[1], std4[2], std4[3]);
+    Norm4 mean, stdv;
+    for (int i = 0; i < 4; ++i) { mean.v[i] = mean4[i]; stdv.v[i] = std4[i]; }
     hipLaunchKernelGGL(decode_cls_boxes_kernel, dim3(mrcnn::ceil_div((int64_t)R * n_class, 256)),
                        dim3(256), 0, mrcnn::as_stream(stream), (const float4 *)roi, cls_loc, ld_loc,
                        (float4 *)cls_bbox, R, n_class, 1.f / scale, mean, stdv, size_h, size_w, 1,

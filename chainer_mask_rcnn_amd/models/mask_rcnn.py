@@ -94,8 +94,9 @@ class MaskRCNN(torch.nn.Module):
         roi_cls_locs = roi_cls_locs.detach()
         if roi_cls_locs.stride(1) != 1:
             roi_cls_locs = roi_cls_locs.contiguous()
-        mean = (_lib.c_f32 * 4)(*self.loc_normalize_mean)
-        std = (_lib.c_f32 * 4)(*self.loc_normalize_std)
+        import ctypes
+        mean = (ctypes.c_double * 4)(*[float(v) for v in self.loc_normalize_mean])
+        std = (ctypes.c_double * 4)(*[float(v) for v in self.loc_normalize_std])
         # RoIs are grouped by image, in order (RegionProposalNetwork): one host read gives the
         # slice bounds.  The device work of every image is queued first; the host halves run
         # afterwards while later images' kernels are still executing.

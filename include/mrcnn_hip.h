@@ -304,10 +304,12 @@ int mrcnn_paste_masks(const float *mask_logits, const int32_t *label, const floa
 /* ---- Inference post-processing (models/mask_rcnn.py:204-265) ---------------- */
 /* Per-class decode: cls_bbox[r,l,:] = clip(loc2bbox(roi[r]/scale,
  * cls_loc[r,l,:]*std+mean), 0, size) for all classes (:225-240). */
-/* mean4/std4 are HOST pointers to 4 floats (loc_normalize_mean/std). */
+/* mean4/std4 are HOST pointers to 4 doubles (loc_normalize_mean/std): the reference builds
+ * them from Python tuples, i.e. as float64 arrays, so `loc * std + mean` is evaluated in double
+ * and rounded to fp32 once (pinned by tests/golden/to_bboxes.npz). */
 int mrcnn_decode_cls_boxes(const float *roi, const float *cls_loc, int ld_loc,
                            float *cls_bbox, int R, int n_class, float scale,
-                           const float *mean4, const float *std4, float size_h,
+                           const double *mean4, const double *std4, float size_h,
                            float size_w, void *stream);
 
 #ifdef __cplusplus

@@ -159,6 +159,106 @@ def main():
     boxes[0] = [3.2, 4.7, 3.9, 5.1]
     np.savez(os.path.join(OUT, 'expand_boxes.npz'), boxes=boxes, scale=16. / 14.,
              out=expand(boxes.copy(), 16. / 14.))
+    # (6) ProposalTargetCreator: the reference's OWN class body
+    #     (models/utils/proposal_target_creator.py:25-184: label assignment, np.random call
+    #     order, mask crop / one-hot / argmax) executed on top of the oracle's restatements of
+    #     the third-party helpers it imports (chainercv bbox_iou / bbox2loc, cv2.resize
+    #     INTER_LINEAR) — those helpers stay "unpinned", the control flow above them is the
+    #     reference's.  Scene: 5 elliptical objects, 600 proposals, global seed 7.
+    from oracle import np_infer
+
+    def cv2_resize(img, dsize):
+        chans = img[..., None] if img.ndim == 2 else img
+        out = np.stack([np_infer.cv_resize_linear(chans[..., c], dsize[1], dsize[0])
+                        for c in range(chans.shape[-1])], axis=-1)
+        return out[..., 0] if out.shape[-1] == 1 else out
+
+    def ref_class(path, name, namespace):
+        tree = ast.parse(open(path).read())
+        node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == name][0]
+        exec(compile(ast.Module(body=[node], type_ignores=[]), path, 'exec'), namespace)
+        return namespace[name]
+
+    ident = lambda a: a
+    PTC = ref_class(os.path.join(models, 'utils', 'proposal_target_creator.py'),
+                    'ProposalTargetCreator',
+                    {'np': np, 'bbox_iou': np_ref.bbox_iou, 'bbox2loc': np_ref.bbox2loc,
+                     'cuda': types.SimpleNamespace(get_array_module=lambda *a: np, to_cpu=ident,
+                                                   to_gpu=ident),
+                     'cv2': types.SimpleNamespace(resize=cv2_resize)})
+    prng = np.random.RandomState(99)
+    H, W, G, R = 240, 320, 5, 600
+    y0 = prng.uniform(0, H - 60, G); x0 = prng.uniform(0, W - 60, G)
+    bbox = np.stack([y0, x0, np.minimum(y0 + prng.uniform(30, 120, G), H),
+                     np.minimum(x0 + prng.uniform(30, 120, G), W)], 1).astype(np.float32)
+    label = prng.randint(0, 80, G).astype(np.int32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    mask = np.zeros((G, H, W), np.int32)
+    for g in range(G):
+        cy, cx = (bbox[g, 0] + bbox[g, 2]) / 2, (bbox[g, 1] + bbox[g, 3]) / 2
+        ry, rx = (bbox[g, 2] - bbox[g, 0]) / 2, (bbox[g, 3] - bbox[g, 1]) / 2
+        mask[g] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0)
+    jit = bbox[prng.randint(0, G, R // 2)] + prng.uniform(-15, 15, (R // 2, 4))
+    ry0 = prng.uniform(0, H - 20, R - R // 2); rx0 = prng.uniform(0, W - 20, R - R // 2)
+    rnd = np.stack([ry0, rx0, ry0 + prng.uniform(10, 150, len(ry0)),
+                    rx0 + prng.uniform(10, 150, len(ry0))], 1)
+    roi = np.concatenate([jit, rnd], 0)
+    roi[:, 0::2] = np.clip(roi[:, 0::2], 0, H); roi[:, 1::2] = np.clip(roi[:, 1::2], 0, W)
+    roi = roi.astype(np.float32)
+    np.random.seed(7)
+    s_roi, loc, lab, m = PTC(n_sample=128)(roi, bbox, label, mask)
+    after = np.random.randint(0, 1 << 30)       # where the global stream stands afterwards
+    np.savez_compressed(os.path.join(OUT, 'proposal_target_creator.npz'), roi=roi, bbox=bbox,
+                        label=label, mask=mask.astype(np.uint8), seed=7, n_sample=128,
+                        sample_roi=s_roi, gt_roi_loc=loc, gt_roi_label=lab, gt_roi_mask=m,
+                        next_randint=after)
+    # (7) Inference post-processing: the reference's own `MaskRCNN._suppress` / `_to_bboxes`
+    #     method bodies (models/mask_rcnn.py:178-265: de-normalisation, per-class threshold and
+    #     NMS loop, rounded-area filter, the argsort-vs-rank keep expression) executed on the
+    #     oracle's restatements of chainercv loc2bbox / non_maximum_suppression and a NumPy
+    #     softmax (helpers unpinned, control flow the reference's).  Given probabilities are
+    #     stored, so consumers need no softmax of their own.
+    def ref_methods(path, cls, names, namespace):
+        tree = ast.parse(open(path).read())
+        node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls][0]
+        body = [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name in names]
+        exec(compile(ast.Module(body=body, type_ignores=[]), path, 'exec'), namespace)
+        return [namespace[n] for n in names]
+
+    def softmax(x):
+        e = np.exp(x - x.max(axis=1, keepdims=True))
+        return types.SimpleNamespace(array=(e / e.sum(axis=1, keepdims=True)).astype(np.float32))
+
+    ns = {'np': np, 'chainer': types.SimpleNamespace(Variable=type('Variable', (), {})),
+          'F': types.SimpleNamespace(softmax=softmax),
+          'cuda': types.SimpleNamespace(to_cpu=lambda a: a),
+          'loc2bbox': np_ref.loc2bbox, 'non_maximum_suppression': np_ref.non_maximum_suppression}
+    suppress, to_bboxes = ref_methods(os.path.join(models, 'mask_rcnn.py'), 'MaskRCNN',
+                                      ['_suppress', '_to_bboxes'], ns)
+    n_class = 81
+    me = types.SimpleNamespace(xp=np, n_class=n_class, nms_thresh=0.5, score_thresh=0.05,
+                               loc_normalize_mean=(0., 0., 0., 0.),
+                               loc_normalize_std=(0.1, 0.1, 0.2, 0.2), _detections_per_im=100)
+    me._suppress = lambda b, p: suppress(me, b, p)
+    drng = np.random.RandomState(5)
+    sizes, scales, Rn = [(600, 900), (480, 640)], [1.6, 1.25], [260, 140]
+    rois, idx = [], []
+    for i, (sz, sc, r) in enumerate(zip(sizes, scales, Rn)):
+        yy0 = drng.uniform(0, sz[0] * sc - 20, r); xx0 = drng.uniform(0, sz[1] * sc - 20, r)
+        rois.append(np.stack([yy0, xx0, np.minimum(yy0 + drng.uniform(10, 300, r), sz[0] * sc),
+                              np.minimum(xx0 + drng.uniform(10, 300, r), sz[1] * sc)], 1))
+        idx.append(np.full(r, i, np.int32))
+    rois = np.concatenate(rois).astype(np.float32)
+    idx = np.concatenate(idx)
+    locs = (drng.standard_normal((len(rois), n_class * 4)) * 0.5).astype(np.float32)
+    logits = (drng.standard_normal((len(rois), n_class)) * 2.5).astype(np.float32)
+    probs = softmax(logits).array
+    bb, ll, ss = to_bboxes(me, locs.copy(), logits.copy(), rois.copy(), idx, sizes, scales)
+    np.savez_compressed(
+        os.path.join(OUT, 'to_bboxes.npz'), roi_cls_locs=locs, roi_scores=logits, probs=probs,
+        rois=rois, roi_indices=idx, sizes=np.array(sizes), scales=np.array(scales),
+        n_det=np.array([len(b) for b in bb]), bbox=np.concatenate(bb), label=np.concatenate(ll),
+        score=np.concatenate(ss))
     print('golden vectors written to', os.path.normpath(OUT))
 
 

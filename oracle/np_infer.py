@@ -2,8 +2,9 @@
 
 NumPy restatement of `MaskRCNN._to_bboxes` / `_suppress`
 (/root/reference/chainer_mask_rcnn/models/mask_rcnn.py:178-265) for one image, built on
-np_ref's loc2bbox / non_maximum_suppression.  "parity unpinned": chainer/chainercv cannot be
-imported here, and the reference has no golden vectors for this path.
+np_ref's loc2bbox / non_maximum_suppression.  The control flow is pinned to the reference's own
+method bodies by tests/golden/to_bboxes.npz (oracle/gen_golden.py section 7); the chainercv
+helpers underneath (loc2bbox, NMS) remain "parity unpinned": chainercv cannot be imported here.
 """
 import numpy as np
 
@@ -14,8 +15,10 @@ def decode_cls_boxes(roi, roi_cls_loc, n_class, scale, size,
                      mean=(0., 0., 0., 0.), std=(0.1, 0.1, 0.2, 0.2)):
     """mask_rcnn.py:220-240: roi / scale, de-normalise, loc2bbox per class, clip."""
     roi = (roi / np.float32(scale)).astype(np.float32)
-    mean = np.tile(np.asarray(mean, np.float32), n_class)
-    std = np.tile(np.asarray(std, np.float32), n_class)
+    # tuples of Python floats -> float64 arrays, as `xp.asarray(self.loc_normalize_mean)` gives:
+    # the de-normalisation runs in double and is rounded once by the astype
+    mean = np.tile(np.asarray(mean), n_class)
+    std = np.tile(np.asarray(std), n_class)
     loc = (roi_cls_loc * std + mean).astype(np.float32).reshape((-1, n_class, 4))
     roi_cls = np.broadcast_to(roi[:, None], loc.shape)
     cls_bbox = np_ref.loc2bbox(roi_cls.reshape((-1, 4)), loc.reshape((-1, 4)))

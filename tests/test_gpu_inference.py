@@ -54,8 +54,9 @@ def test_decode_cls_boxes_bit_exact(dev):
     R, n_class = 500, 81
     roi, loc, _ = _make(rng, R, n_class, 960, 1440)
     out = torch.empty((R, n_class, 4), device=dev)
-    mean = (_lib.c_f32 * 4)(0., 0., 0., 0.)
-    std = (_lib.c_f32 * 4)(0.1, 0.1, 0.2, 0.2)
+    import ctypes
+    mean = (ctypes.c_double * 4)(0., 0., 0., 0.)
+    std = (ctypes.c_double * 4)(0.1, 0.1, 0.2, 0.2)
     roi_d, loc_d = torch.tensor(roi, device=dev), torch.tensor(loc, device=dev)   # keep alive
     _lib.call('mrcnn_decode_cls_boxes', _lib.ptr(roi_d), _lib.ptr(loc_d), n_class * 4,
               _lib.ptr(out), R, n_class, 1.6, mean, std, 600., 900., _lib.stream_ptr())
@@ -124,3 +125,25 @@ def test_predict_end_to_end_api(dev):
         if len(b):
             assert b[:, 0::2].min() >= 0 and b[:, 0::2].max() <= img.shape[1]
             assert (s > 0.05).all() and l.min() >= 0 and l.max() < 80
+
+
+def test_to_bboxes_matches_reference_method_fixture(dev, golden_dir):
+    """The device path of MaskRCNN._to_bboxes (softmax, per-class decode, batched threshold /
+    sort / NMS, host finish) on the inputs of tests/golden/to_bboxes.npz, whose outputs come
+    from the reference's own method bodies (oracle/gen_golden.py section 7)."""
+    import os
+    d = np.load(os.path.join(golden_dir, 'to_bboxes.npz'))
+    n_class = d['probs'].shape[1]
+    model = cmr.models.MaskRCNN(None, None, None, mean=None)
+    model.head = type('H', (), {'n_class': n_class, 'mask_size': 14})()
+    t = lambda a: torch.tensor(a, device=dev)
+    bboxes, labels, scores = model._to_bboxes(
+        t(d['roi_cls_locs']), t(d['roi_scores']), t(d['rois']), t(d['roi_indices']),
+        [tuple(int(v) for v in s) for s in d['sizes']], [float(s) for s in d['scales']])
+    lo = 0
+    for i, n in enumerate(d['n_det']):
+        assert len(bboxes[i]) == n
+        assert np.array_equal(labels[i], d['label'][lo:lo + n])
+        assert np.array_equal(bboxes[i], d['bbox'][lo:lo + n])
+        np.testing.assert_allclose(scores[i], d['score'][lo:lo + n], rtol=2e-6, atol=0)
+        lo += n

@@ -141,3 +141,24 @@ def test_shifted_anchor_and_expand_boxes_pinned_to_reference(golden_dir):
     e = np.load(os.path.join(golden_dir, 'expand_boxes.npz'))
     out = np_infer.expand_boxes(e['boxes'], float(e['scale']))
     assert out.dtype == e['out'].dtype and np.array_equal(out, e['out'])
+
+
+def test_inference_postprocessing_pinned_to_reference_methods(golden_dir):
+    """Fixture produced by the reference's own `MaskRCNN._to_bboxes` / `_suppress` bodies
+    (models/mask_rcnn.py:178-265) on top of restated loc2bbox / NMS (oracle/gen_golden.py
+    section 7): the oracle's decode -> suppress -> finish pipeline reproduces it exactly."""
+    import os
+    from oracle import np_infer
+    d = np.load(os.path.join(golden_dir, 'to_bboxes.npz'))
+    n_class = d['probs'].shape[1]
+    lo = 0
+    for i, n in enumerate(d['n_det']):
+        sel = d['roi_indices'] == i
+        cls_bbox = np_infer.decode_cls_boxes(d['rois'][sel], d['roi_cls_locs'][sel], n_class,
+                                             float(d['scales'][i]), tuple(d['sizes'][i]))
+        b, l, s = np_infer.finish(*np_infer.suppress(cls_bbox, d['probs'][sel], n_class))
+        assert len(b) == n
+        assert np.array_equal(b, d['bbox'][lo:lo + n])
+        assert l.dtype == np.int32 and np.array_equal(l, d['label'][lo:lo + n])
+        assert np.array_equal(s, d['score'][lo:lo + n])
+        lo += n

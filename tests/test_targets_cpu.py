@@ -80,3 +80,29 @@ def test_host_bbox_utils_match_oracle():
                           np_ref.enumerate_shifted_anchor(ab, 16, 51, 84))
     img = rng.uniform(size=(23, 31)).astype(np.float32)
     assert np.array_equal(B.resize_bilinear(img, 14, 14), np_ref.resize_bilinear(img, 14, 14))
+
+
+def test_proposal_target_creator_pinned_to_reference_class(golden_dir):
+    """Fixture produced by the reference's own ProposalTargetCreator class body
+    (models/utils/proposal_target_creator.py:25-184) running on the oracle's restatements of
+    bbox_iou / bbox2loc / cv2.resize (oracle/gen_golden.py section 6): sampled RoIs, labels,
+    14x14 mask targets and the position of the global np.random stream afterwards must be
+    identical for the oracle's literal restatement and for the product's split sample /
+    mask_targets implementation."""
+    import os
+    d = np.load(os.path.join(golden_dir, 'proposal_target_creator.npz'))
+    mask = d['mask'].astype(np.int32)
+    for make in (np_targets.ProposalTargetCreator, ProposalTargetCreator):
+        np.random.seed(int(d['seed']))
+        s_roi, loc, lab, m = make(n_sample=int(d['n_sample']))(d['roi'], d['bbox'], d['label'], mask)
+        assert np.random.randint(0, 1 << 30) == int(d['next_randint'])
+        assert np.array_equal(s_roi, d['sample_roi'])
+        assert lab.dtype == np.int32 and np.array_equal(lab, d['gt_roi_label'])
+        np.testing.assert_allclose(loc, d['gt_roi_loc'], rtol=1e-6, atol=1e-6)
+        assert m.dtype == np.int32 and np.array_equal(m, d['gt_roi_mask'])
+    # the product's two halves, as MaskRCNNTrainChain calls them
+    ptc = ProposalTargetCreator(n_sample=int(d['n_sample']))
+    np.random.seed(int(d['seed']))
+    s_roi, loc, lab, job = ptc.sample(d['roi'], d['bbox'], d['label'])
+    assert np.random.randint(0, 1 << 30) == int(d['next_randint'])   # mask_targets draws nothing
+    assert np.array_equal(ptc.mask_targets(job, mask), d['gt_roi_mask'])
