@@ -259,6 +259,74 @@ def main():
         rois=rois, roi_indices=idx, sizes=np.array(sizes), scales=np.array(scales),
         n_det=np.array([len(b) for b in bb]), bbox=np.concatenate(bb), label=np.concatenate(ll),
         score=np.concatenate(ss))
+    # (8) localisation loss: the reference's own `_smooth_l1_loss` / `_fast_rcnn_loc_loss`
+    #     (models/mask_rcnn_train_chain.py:192-213) with chainer's elementwise F.absolute /
+    #     F.square / F.sum mapped to the NumPy functions of the same meaning.
+    class Var(np.ndarray):
+        @property
+        def data(self):
+            return self.view(np.ndarray)
+
+    tc = os.path.join(models, 'mask_rcnn_train_chain.py')
+    lns = {'np': np, 'F': types.SimpleNamespace(absolute=np.absolute, square=np.square, sum=np.sum),
+           'chainer': types.SimpleNamespace(cuda=types.SimpleNamespace(get_array_module=lambda *a: np))}
+    ref_function(tc, '_smooth_l1_loss', lns)
+    loc_loss = ref_function(tc, '_fast_rcnn_loc_loss', lns)
+    lrng = np.random.RandomState(21)
+    pred = (lrng.standard_normal((700, 4)) * 0.7).astype(np.float32)
+    gt = (lrng.standard_normal((700, 4)) * 0.7).astype(np.float32)
+    lab = lrng.choice(np.array([-1, 0, 0, 1, 5, 80], np.int32), 700)
+    np.savez(os.path.join(OUT, 'loc_loss.npz'), pred=pred, gt=gt, label=lab,
+             loss_sigma3=np.float64(loc_loss(pred.view(Var), gt, lab, 3.)),
+             loss_sigma1=np.float64(loc_loss(pred.view(Var), gt, lab, 1.)))
+    # (9) image I/O of predict: the reference's own `MaskRCNN.prepare` (models/mask_rcnn.py:
+    #     152-176: scale rule, transposes, mean subtraction) and `segm_results` (:63-107: box
+    #     expansion, int truncation, clipping and paste) executed with `cv2.resize` mapped to the
+    #     oracle's INTER_LINEAR restatement (cv2 is not installable here: that call stays
+    #     unpinned, everything around it is the reference's).
+    def cv2_resize_api(img, dsize, fx=None, fy=None):
+        chans = img[..., None] if img.ndim == 2 else img
+        if dsize is None:
+            out_h, out_w = int(np.round(img.shape[0] * fy)), int(np.round(img.shape[1] * fx))
+            sy, sx = 1. / fy, 1. / fx
+        else:
+            (out_w, out_h), sy, sx = dsize, None, None
+        out = np.stack([np_infer.cv_resize_linear(chans[..., c].astype(np.float32), int(out_h),
+                                                  int(out_w), sy, sx)
+                        for c in range(chans.shape[-1])], axis=-1)
+        return out[..., 0] if img.ndim == 2 else out
+
+    cvns = types.SimpleNamespace(resize=cv2_resize_api)
+    mpath = os.path.join(models, 'mask_rcnn.py')
+    prepare, = ref_methods(mpath, 'MaskRCNN', ['prepare'], {'np': np, 'cv2': cvns})
+    mean = np.array([123.152, 115.903, 103.063], np.float32)[:, None, None]
+    pm = types.SimpleNamespace(min_size=160, max_size=240, mean=mean)
+    irng = np.random.RandomState(31)
+    imgs = [irng.randint(0, 256, (3, 97, 131)).astype(np.uint8),
+            irng.uniform(0, 255, (3, 120, 90)).astype(np.float32),
+            irng.randint(0, 256, (3, 60, 200)).astype(np.uint8)]
+    outs, psizes, pscales = prepare(pm, imgs)
+    np.savez_compressed(os.path.join(OUT, 'prepare.npz'), min_size=160, max_size=240,
+                        mean=mean.ravel(), img0=imgs[0], img1=imgs[1], img2=imgs[2],
+                        out0=outs[0], out1=outs[1], out2=outs[2], sizes=np.array(psizes),
+                        scales=np.array(pscales))
+
+    sns = {'np': np, 'cv2': cvns}
+    sns['expand_boxes'] = expand
+    segm = ref_function(mpath, 'segm_results', sns)
+    Dn, n_fg, M, im_h, im_w = 24, 80, 14, 150, 210
+    logits = (irng.standard_normal((Dn, n_fg, M, M)) * 3).astype(np.float32)
+    slabel = irng.randint(0, n_fg, Dn).astype(np.int32)
+    sy0 = irng.uniform(-10, im_h - 5, Dn); sx0 = irng.uniform(-10, im_w - 5, Dn)
+    sbox = np.stack([sy0, sx0, sy0 + irng.uniform(1, 120, Dn), sx0 + irng.uniform(1, 150, Dn)],
+                    1).astype(np.float32)
+    sbox[0] = [3.2, 4.7, 3.9, 5.1]
+    prob = (1. / (1. + np.exp(-logits.astype(np.float64)))).astype(np.float32)   # F.sigmoid
+    masks = segm(sbox, slabel, prob, im_h, im_w)
+    # only the selected class planes are needed by a consumer
+    np.savez_compressed(os.path.join(OUT, 'segm_results.npz'), bbox=sbox, label=slabel,
+                        logits_sel=logits[np.arange(Dn), slabel], n_fg=n_fg, im_h=im_h, im_w=im_w,
+                        masks=np.packbits(masks, axis=-1), masks_shape=np.array(masks.shape))
     print('golden vectors written to', os.path.normpath(OUT))
 
 

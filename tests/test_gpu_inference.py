@@ -147,3 +147,23 @@ def test_to_bboxes_matches_reference_method_fixture(dev, golden_dir):
         assert np.array_equal(bboxes[i], d['bbox'][lo:lo + n])
         np.testing.assert_allclose(scores[i], d['score'][lo:lo + n], rtol=2e-6, atol=0)
         lo += n
+
+
+def test_image_io_matches_reference_body_fixtures(dev, golden_dir):
+    """Device prepare / mask paste vs the fixtures produced by the reference's own
+    `MaskRCNN.prepare` and `segm_results` bodies (oracle/gen_golden.py section 9)."""
+    import os
+    from test_oracle_boxes import _segm_fixture
+    d = np.load(os.path.join(golden_dir, 'prepare.npz'))
+    model = cmr.models.MaskRCNNResNet(50, n_fg_class=80, min_size=int(d['min_size']),
+                                      max_size=int(d['max_size']), mean=tuple(d['mean']),
+                                      anchor_scales=(2, 4, 8, 16, 32), roi_size=14).to(dev)
+    x, sizes, scales = model.prepare([d['img%d' % i] for i in range(3)])
+    x = x.cpu().numpy()
+    for i in range(3):
+        ref = d['out%d' % i]
+        assert scales[i] == float(d['scales'][i]) and tuple(sizes[i]) == tuple(d['sizes'][i])
+        np.testing.assert_allclose(x[i, :, :ref.shape[1], :ref.shape[2]], ref, rtol=0, atol=2e-4)
+    bbox, label, logits, im_h, im_w, masks = _segm_fixture(golden_dir)
+    got = model._to_masks([bbox], [label], None, [torch.tensor(logits, device=dev)], [(im_h, im_w)])
+    assert got[0].shape == masks.shape and (got[0] != masks).mean() < 1e-6

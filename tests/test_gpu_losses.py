@@ -117,3 +117,11 @@ def test_sgd_momentum_wd(dev):
     p2, v2 = np_ref.momentum_sgd_wd(p, g, v, 0.02)
     np.testing.assert_allclose(pt.cpu().numpy(), p2, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(vt.cpu().numpy(), v2, rtol=1e-5, atol=1e-6)
+
+
+def test_loc_loss_matches_reference_function_fixture(dev, golden_dir):
+    import os
+    d = np.load(os.path.join(golden_dir, 'loc_loss.npz'))
+    for sigma, key in ((3., 'loss_sigma3'), (1., 'loss_sigma1')):
+        loss = F.fast_rcnn_loc_loss(_t(d['pred'], dev), _t(d['gt'], dev), _t(d['label'], dev), sigma)
+        np.testing.assert_allclose(loss.item(), float(d[key]), rtol=1e-5)

@@ -162,3 +162,30 @@ def test_inference_postprocessing_pinned_to_reference_methods(golden_dir):
         assert l.dtype == np.int32 and np.array_equal(l, d['label'][lo:lo + n])
         assert np.array_equal(s, d['score'][lo:lo + n])
         lo += n
+
+
+def _segm_fixture(golden_dir):
+    import os
+    d = np.load(os.path.join(golden_dir, 'segm_results.npz'))
+    D, M = d['logits_sel'].shape[:2]
+    logits = np.zeros((D, int(d['n_fg']), M, M), np.float32)
+    logits[np.arange(D), d['label']] = d['logits_sel']
+    shape = tuple(d['masks_shape'])
+    masks = np.unpackbits(d['masks'], axis=-1)[..., :shape[-1]].astype(bool)
+    return d['bbox'], d['label'], logits, int(d['im_h']), int(d['im_w']), masks
+
+
+def test_image_io_pinned_to_reference_bodies(golden_dir):
+    """prepare.npz / segm_results.npz come from the reference's own `MaskRCNN.prepare`
+    (models/mask_rcnn.py:152-176) and `segm_results` (:63-107) with cv2.resize mapped to the
+    oracle's INTER_LINEAR restatement (oracle/gen_golden.py section 9)."""
+    import os
+    from oracle import np_infer
+    d = np.load(os.path.join(golden_dir, 'prepare.npz'))
+    for i in range(3):
+        out, scale = np_infer.prepare(d['img%d' % i], d['mean'], int(d['min_size']), int(d['max_size']))
+        assert scale == float(d['scales'][i])
+        assert out.dtype == np.float32 and np.array_equal(out, d['out%d' % i])
+    bbox, label, logits, im_h, im_w, masks = _segm_fixture(golden_dir)
+    got = np_infer.segm_results(bbox, label, logits, im_h, im_w)
+    assert got.shape == masks.shape and np.array_equal(got, masks) and masks.any()

@@ -142,3 +142,13 @@ def test_momentum_sgd():
     opt.step()
     p2, v2 = np_ref.momentum_sgd_wd(p, g, v, 0.01)
     np.testing.assert_allclose(p2, pt.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_loc_loss_pinned_to_reference_functions(golden_dir):
+    """tests/golden/loc_loss.npz comes from the reference's own `_fast_rcnn_loc_loss` /
+    `_smooth_l1_loss` (models/mask_rcnn_train_chain.py:192-213, oracle/gen_golden.py section 8)."""
+    import os
+    d = np.load(os.path.join(golden_dir, 'loc_loss.npz'))
+    for sigma, key in ((3., 'loss_sigma3'), (1., 'loss_sigma1')):
+        loss, _ = np_ref.fast_rcnn_loc_loss(d['pred'], d['gt'], d['label'], sigma)
+        np.testing.assert_allclose(loss, float(d[key]), rtol=1e-6)
