@@ -54,14 +54,15 @@ SIGNATURES = {
     'mrcnn_nms_sorted': (c_int, [c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mrcnn_nms_sorted_batched': (c_int, [c_vp, c_vp, c_int, c_int, c_f32, c_int, c_vp, c_vp,
                                          c_vp, c_vp]),
-    'mrcnn_conv2d_fwd': (c_int, [_DP] + [c_vp] * 7 + [c_int, c_vp]),
+    'mrcnn_conv2d_split_workspace_bytes': (c_i64, []),
+    'mrcnn_conv2d_fwd': (c_int, [_DP] + [c_vp] * 7 + [c_int, c_vp, c_vp]),
     'mrcnn_conv2d_dgrad': (c_int, [_DP, c_vp, c_vp, c_vp, c_int, c_vp]),
     'mrcnn_conv2d_wgrad_workspace_bytes': (c_i64, [_DP]),
     'mrcnn_conv2d_wgrad': (c_int, [_DP, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'mrcnn_conv2d_dgrad_ex': (c_int, [_DP, c_vp, c_vp, c_vp, c_int] + [c_vp] * 7),
+    'mrcnn_conv2d_dgrad_ex': (c_int, [_DP, c_vp, c_vp, c_vp, c_int] + [c_vp] * 8),
     'mrcnn_conv2d_wgrad_ex': (c_int, [_DP] + [c_vp] * 8),
     'mrcnn_filter_flip_transpose': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
-    'mrcnn_conv2d_dgrad_wt': (c_int, [_DP, c_vp, c_vp, c_vp, c_int] + [c_vp] * 7),
+    'mrcnn_conv2d_dgrad_wt': (c_int, [_DP, c_vp, c_vp, c_vp, c_int] + [c_vp] * 8),
     'mrcnn_conv_stem_fwd': (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp]),
     'mrcnn_deconv2x2s2_fwd': (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     'mrcnn_deconv2x2s2_dgrad': (c_int, [c_vp] * 3 + [c_int] * 5 + [c_vp]),

@@ -104,8 +104,9 @@ struct GemmParams {
     int out_mode;
     int oh, ow, ko;      // OUT_STRIDED: gx spatial dims; OUT_DECONV: ko = out channels
     int stem;            // FWD: stem gather (8 pixels x 4 ch per K slice)
-    int split_len;       // WGRAD: pixels per split
-    int64_t split_stride;// WGRAD: floats between split slabs
+    int split_len;       // WGRAD: pixels per split; FWD/DGRAD: K slices per split (0: no split)
+    int64_t split_stride;// floats between split slabs
+    int out_row0;        // FWD/DGRAD split launches: first row of the slab (subtracted)
     // Fused backward of the producing conv's epilogue, applied while gy is staged
     // (DGRAD A operand / WGRAD A' operand):  g = gy * (mask_y > 0) * in_scale[k]
     const float *mask_y;   // output of the ReLU that followed the conv (same shape as gy) or NULL
@@ -118,6 +119,7 @@ struct GemmParams {
     // WGRAD epilogue: gw[k, :] *= scale[k]
     const float *res_g, *res_y, *out_mask_y;
     int prof_kind;       // host only: profiler bucket of the 128x128 launch
+    float *split_ws;     // host only: caller's split-K workspace (kSplitWsBytes) or NULL
     unsigned a_bytes, b_bytes, c_bytes;  // buffer extents (bytes) of A (and mask_y), B, C
 };
 
@@ -276,7 +278,14 @@ conv_gemm_kernel(const GemmParams p)
 
     const int adv_x = BK % p.gq, adv_y = (BK / p.gq) % p.gp, adv_n = BK / (p.gp * p.gq);
     const int cprs = (MODE == WGRAD) ? 1 : (p.Kc + BK - 1) / BK;  // K slices per (r,s)
-    const int nslices = (MODE == WGRAD) ? (k_end - k_begin + BK - 1) / BK : p.R * p.S * cprs;
+    // FWD/DGRAD split-K (leftover rows of a small-M problem, see launch()): this workgroup
+    // runs slices [kt0, kt0 + nslices) and writes raw partial sums into its slab
+    int kt0 = 0;
+    int nslices = (MODE == WGRAD) ? (k_end - k_begin + BK - 1) / BK : p.R * p.S * cprs;
+    if (MODE != WGRAD && p.split_len > 0) {
+        kt0 = split * p.split_len;
+        nslices = max(0, min(nslices - kt0, p.split_len));
+    }
 
     float4 ra[AV], rb[BV];
     float4 rm[HAS_MASK ? AV : 1];
@@ -320,6 +329,7 @@ conv_gemm_kernel(const GemmParams p)
     // the same 32-channel slab of neighbouring pixels, which stays in the CU's L1.
     auto load_slice = [&](int kt) {
         if (FWDLIKE || MODE == DGRAD) {
+            kt += kt0;
             const int chunk = kt / RS;
             const int rs = kt - chunk * RS;
             const int c0 = chunk * BK;
@@ -560,7 +570,7 @@ conv_gemm_kernel(const GemmParams p)
     // Per 32x32 MFMA tile: compute the 16 element offsets, issue every auxiliary load
     // (residual / accumulate / shortcut gradient) back to back, then combine and store.
     const float *out_base = p.C;
-    if (MODE == WGRAD) out_base += (int64_t)split * p.split_stride;
+    out_base += (int64_t)split * p.split_stride;
     const __amdgpu_buffer_rsrc_t rC = make_rsrc(out_base, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rRes = make_rsrc(p.residual, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rResG = make_rsrc(p.res_g, p.c_bytes);
@@ -607,7 +617,7 @@ conv_gemm_kernel(const GemmParams p)
                         else
                             o = ((n * (2 * p.gp) + 2 * gy) * (2 * p.gq) + 2 * gx) * p.ko + col_off;
                     } else {
-                        o = row * p.ldc + col_off;
+                        o = (row - p.out_row0) * p.ldc + col_off;
                     }
                     off[q] = (col_ok && row < p.M) ? 4u * (unsigned)o : kOOB;
                 }
@@ -720,6 +730,94 @@ void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
     launch_kernel<TM, TN, MODE>(p, blocks, splits, s);
 }
 
+// ---- split-K for the leftover rows of a small-M forward / dgrad ----------------------------
+// 64x64 tiles are all resident at once, so a launch of T tiles costs ceil(T / 256) tile-times
+// on the busiest CU (T = 536 -> 3, although the average CU has 2.09).  The rows of the whole
+// multiples of 256 tiles run as usual; the leftover rows (< 154 tiles) are cut along K into
+// `splits` short workgroups that spread over all CUs, write raw partial sums into slabs, and
+// a small kernel sums the slabs in order and applies the epilogue (deterministic).
+constexpr int64_t kSplitWsBytes = 154ll * 64 * 64 * 16 * 4;
+
+struct FixParams {
+    const float *ws;
+    float *C;
+    const float *bias, *scale, *shift, *residual, *res_g, *res_y, *out_mask_y;
+    int splits, rows, N, row0, ldc, flags;
+    int64_t stride;
+};
+
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(const FixParams f)
+{
+    const int n4 = f.N / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)f.rows * n4) return;
+    const int r = (int)(i / n4), c = (int)(i - (int64_t)r * n4) * 4;
+    float4 a = *reinterpret_cast<const float4 *>(f.ws + (int64_t)r * f.N + c);
+    for (int s = 1; s < f.splits; ++s) {
+        const float4 v = *reinterpret_cast<const float4 *>(f.ws + s * f.stride + (int64_t)r * f.N + c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    const int64_t off = (int64_t)(f.row0 + r) * f.ldc + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x = v[k];
+        if (f.flags & MRCNN_EPI_BIAS) x += f.bias[c + k];
+        if (f.flags & MRCNN_EPI_AFFINE) x = x * f.scale[c + k] + (f.shift ? f.shift[c + k] : 0.f);
+        if (f.flags & MRCNN_EPI_RESIDUAL) x += f.residual[off + k];
+        if (f.flags & MRCNN_EPI_ACCUM) x += f.C[off + k];
+        if (f.res_g) x += (!f.res_y || f.res_y[off + k] > 0.f) ? f.res_g[off + k] : 0.f;
+        if (f.flags & MRCNN_EPI_RELU) x = fmaxf(x, 0.f);
+        if (f.out_mask_y) x = f.out_mask_y[off + k] > 0.f ? x : 0.f;
+        v[k] = x;
+    }
+    *reinterpret_cast<float4 *>(f.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <int MODE>
+void launch_small(const GemmParams &p, hipStream_t s)
+{
+    const int64_t tm = mrcnn::ceil_div(p.M, 64), tn = mrcnn::ceil_div(p.N, 64);
+    const int64_t T = tm * tn, whole = (T / 256) * 256, rem = T - whole;
+    const int total_slices = p.R * p.S * (int)mrcnn::ceil_div(p.Kc, BK);
+    const bool can_split = p.split_ws && MODE != WGRAD && p.out_mode == OUT_PLAIN && !p.stem &&
+                           p.N % 4 == 0 && p.ldc == p.N && whole > 0 && whole <= 1024 && rem > 0 &&
+                           rem < 154 && total_slices >= 8;   // beyond 4 tile-times per CU the
+                                                             // two extra launches cost more than
+                                                             // the imbalance
+    const int rows_main = can_split ? (int)std::min<int64_t>(p.M, (whole / tn) * 64) : p.M;
+    const int64_t left_tiles = mrcnn::ceil_div(p.M - rows_main, 64) * tn;
+    int splits = 1;
+    if (can_split && rows_main < p.M)
+        splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, total_slices / 4),
+                                                               mrcnn::ceil_div(256, left_tiles)));
+    if (splits < 2) {
+        launch_tiles<1, 1, MODE>(p, 0, p.M, 1, s);
+        return;
+    }
+    launch_tiles<1, 1, MODE>(p, 0, rows_main, 1, s);
+    const int rows_left = p.M - rows_main;
+    GemmParams q = p;
+    q.C = p.split_ws;
+    q.flags = 0;
+    q.bias = q.scale = q.shift = q.residual = q.res_g = q.res_y = q.out_mask_y = nullptr;
+    q.split_len = (int)mrcnn::ceil_div(total_slices, splits);
+    splits = (int)mrcnn::ceil_div(total_slices, q.split_len);
+    q.split_stride = (int64_t)rows_left * p.N;
+    q.out_row0 = rows_main;
+    q.c_bytes = (unsigned)(q.split_stride * 4);
+    launch_tiles<1, 1, MODE>(q, rows_main, p.M, splits, s);
+    FixParams f = {};
+    f.ws = p.split_ws; f.C = p.C;
+    f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.residual = p.residual;
+    f.res_g = p.res_g; f.res_y = p.res_y; f.out_mask_y = p.out_mask_y;
+    f.splits = splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_main; f.ldc = p.ldc;
+    f.flags = p.flags; f.stride = q.split_stride;
+    const int64_t n = (int64_t)rows_left * (p.N / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0,
+                       s, f);
+}
+
 // FWD / DGRAD launch policy.  With T 128x128 tiles and 512 resident workgroups a launch
 // takes ceil(T/512) "rounds"; when the last round would be mostly empty (e.g. T = 536 or
 // 1568) the rows of the full rounds run as 128x128 tiles and the leftover rows as a second,
@@ -731,7 +829,7 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
     const int64_t T = tm * tn;
     const bool big_ok = p.N > 64 && p.M > 64;
     if (!big_ok || T < 384) {
-        launch_tiles<1, 1, MODE>(p, 0, p.M, splits, s);
+        launch_small<MODE>(p, s);
     } else {
         // whole "rounds" of k workgroups per CU (k = 3, 2, 1): pick the round size that leaves
         // the smallest leftover, run the leftover rows as 64x64 tiles
@@ -810,9 +908,12 @@ extern "C" int mrcnn_gemm_trace_read(unsigned long long *host, int n)
 }
 #endif
 
+extern "C" int64_t mrcnn_conv2d_split_workspace_bytes(void) { return kSplitWsBytes; }
+
 extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                                 const float *bias, const float *scale, const float *shift,
-                                const float *residual, float *y, int epi_flags, void *stream)
+                                const float *residual, float *y, int epi_flags, void *split_ws,
+                                void *stream)
 {
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
@@ -828,6 +929,7 @@ extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const 
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
     p.lda = d->C; p.ldb = d->R * d->S * d->C; p.ldc = d->K;
     p.flags = epi_flags; p.out_mode = OUT_PLAIN; p.prof_kind = mrcnn::PROF_CONV_FWD_128;
+    p.split_ws = (float *)split_ws;
     if (int rc = set_extents(p, (int64_t)d->N * d->H * d->W * d->C, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->P * d->Q * d->K))
         return rc;
@@ -861,20 +963,20 @@ extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, 
                                      float *gx, int epi_flags, const float *mask_y,
                                      const float *in_scale, const float *res_g,
                                      const float *res_y, const float *out_mask_y,
-                                     const float *out_scale, void *stream);
+                                     const float *out_scale, void *split_ws, void *stream);
 
 extern "C" int mrcnn_conv2d_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w,
                                   float *gx, int epi_flags, void *stream)
 {
     return mrcnn_conv2d_dgrad_ex(d, gy, w, gx, epi_flags, nullptr, nullptr, nullptr, nullptr,
-                                 nullptr, nullptr, stream);
+                                 nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, const float *w,
                                      float *gx, int epi_flags, const float *mask_y,
                                      const float *in_scale, const float *res_g,
                                      const float *res_y, const float *out_mask_y,
-                                     const float *out_scale, void *stream)
+                                     const float *out_scale, void *split_ws, void *stream)
 {
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(!res_y || res_g, "conv2d_dgrad: res_y without res_g");
@@ -893,6 +995,7 @@ extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, 
     p.lda = d->K; p.ldb = d->R * d->S * d->C; p.ldc = d->C;
     p.flags = epi_flags | (out_scale ? MRCNN_EPI_AFFINE : 0);
     p.prof_kind = mrcnn::PROF_CONV_DGRAD_128;
+    p.split_ws = (float *)split_ws;
     if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->H * d->W * d->C))
         return rc;
@@ -952,7 +1055,7 @@ extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, 
                                      float *gx, int epi_flags, const float *mask_y,
                                      const float *in_scale, const float *res_g,
                                      const float *res_y, const float *out_mask_y,
-                                     const float *out_scale, void *stream)
+                                     const float *out_scale, void *split_ws, void *stream)
 {
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(d->stride == 1, "conv2d_dgrad_wt: stride must be 1");
@@ -965,6 +1068,7 @@ extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, 
     p.mask_y = mask_y; p.in_scale = in_scale; p.res_g = res_g; p.res_y = res_y;
     p.out_mask_y = out_mask_y; p.scale = out_scale;
     p.prof_kind = mrcnn::PROF_CONV_DGRAD_128;
+    p.split_ws = (float *)split_ws;
     p.M = d->N * d->H * d->W; p.N = d->C; p.Kc = d->K;
     p.gp = d->H; p.gq = d->W; p.sh = d->P; p.sw = d->Q;
     p.R = d->R; p.S = d->S; p.stride = 1; p.pad = d->R - 1 - d->pad;
@@ -1078,7 +1182,7 @@ extern "C" int mrcnn_deconv2x2s2_dgrad(const float *gy, const float *w, float *g
 {
     // gx = conv2x2/2(gy) with KRSC filter w (C,2,2,K)
     mrcnn_conv_desc d = {N, 2 * H, 2 * W, K, C, 2, 2, 2, 0, H, W};
-    return mrcnn_conv2d_fwd(&d, gy, w, nullptr, nullptr, nullptr, nullptr, gx, 0, stream);
+    return mrcnn_conv2d_fwd(&d, gy, w, nullptr, nullptr, nullptr, nullptr, gx, 0, nullptr, stream);
 }
 
 extern "C" int64_t mrcnn_deconv2x2s2_wgrad_workspace_bytes(int N, int H, int W, int C, int K)

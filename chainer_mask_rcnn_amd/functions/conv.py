@@ -41,6 +41,12 @@ def _colsum(g2d_ptr, M, C, out, device):
     _lib.call('mrcnn_colsum', g2d_ptr, _lib.ptr(out), M, C, _lib.ptr(ws), _lib.stream_ptr())
 
 
+def split_ws(device):
+    """Scratch for the split-K leftover launches of small-M forward / dgrad GEMMs (cached per
+    device and stream-ordered: safe because every user runs on the compute stream)."""
+    return _lib.workspace(_lib.load().mrcnn_conv2d_split_workspace_bytes(), device, 'conv-split')
+
+
 def epilogue_bwd(gy, y=None, scale=None):
     """g = gy * (y > 0) * scale[c] on NHWC tensors (any of y/scale may be None)."""
     N, C = gy.shape[0], gy.shape[1]
@@ -73,7 +79,7 @@ class _Conv2dFn(torch.autograd.Function):
         y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
         _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(b),
                   _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(y), flags,
-                  _lib.stream_ptr())
+                  _lib.ptr(split_ws(x.device)), _lib.stream_ptr())
         ctx.d = d
         ctx.relu = relu
         ctx.has_bias = b is not None
@@ -250,7 +256,8 @@ def _fwd_raw(x, Wc, d, scale, shift, residual, relu):
         | (EPI_RELU if relu else 0)
     y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
     _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), None, _lib.ptr(scale),
-              _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(y), flags, _lib.stream_ptr())
+              _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(y), flags, _lib.ptr(split_ws(x.device)),
+              _lib.stream_ptr())
     return y
 
 
@@ -284,14 +291,15 @@ def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, acc
         _lib.call('mrcnn_conv2d_dgrad_wt', ctx_desc(d), _lib.ptr(g), _lib.ptr(wT), _lib.ptr(gx),
                   EPI_ACCUM if accum else 0, _lib.ptr(mask_y), _lib.ptr(in_scale),
                   _lib.ptr(res_g), _lib.ptr(res_y), _lib.ptr(out_mask_y), _lib.ptr(out_scale),
-                  _lib.stream_ptr())
+                  _lib.ptr(split_ws(g.device)), _lib.stream_ptr())
         return gx
     if fold_scale is not None:
         assert in_scale is None
         in_scale = fold_scale
     _lib.call('mrcnn_conv2d_dgrad_ex', ctx_desc(d), _lib.ptr(g), _lib.ptr(Wc), _lib.ptr(gx),
               EPI_ACCUM if accum else 0, _lib.ptr(mask_y), _lib.ptr(in_scale), _lib.ptr(res_g),
-              _lib.ptr(res_y), _lib.ptr(out_mask_y), _lib.ptr(out_scale), _lib.stream_ptr())
+              _lib.ptr(res_y), _lib.ptr(out_mask_y), _lib.ptr(out_scale),
+              _lib.ptr(split_ws(g.device)), _lib.stream_ptr())
     return gx
 
 

@@ -147,10 +147,17 @@ typedef struct {
  * residual add and ReLU of chainer's BottleneckA/B (call sites
  * models/region_proposal_network.py:75-80,124-131, models/mask_rcnn_resnet.py:131-143,
  * chainer ResNet50Layers via models/resnet_extractor.py:93).
- * y = epi( conv(x, w) ).  scale/shift/bias/residual may be NULL when unused. */
+ * y = epi( conv(x, w) ).  scale/shift/bias/residual may be NULL when unused.
+ * split_ws (forward and backward-data entry points): NULL or a scratch buffer of
+ * mrcnn_conv2d_split_workspace_bytes() bytes.  With it, a small-M problem whose 64x64 tiles
+ * do not divide evenly over the 256 CUs (e.g. 536 tiles: the busiest CU would run 3, the
+ * average 2.09) runs its leftover rows split along K into many short workgroups whose partial
+ * sums are combined, in a fixed order, by a small epilogue kernel. */
+int64_t mrcnn_conv2d_split_workspace_bytes(void);
 int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                      const float *bias, const float *scale, const float *shift,
-                     const float *residual, float *y, int epi_flags, void *stream);
+                     const float *residual, float *y, int epi_flags, void *split_ws,
+                     void *stream);
 /* Gradient w.r.t. the input.  gy (N,P,Q,K) -> gx (N,H,W,C).  With
  * MRCNN_EPI_ACCUM gx += result (fan-in of several consumers). */
 int mrcnn_conv2d_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w,
@@ -183,7 +190,8 @@ int mrcnn_conv2d_wgrad(const mrcnn_conv_desc *d, const float *x, const float *gy
 int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, const float *w,
                           float *gx, int epi_flags, const float *mask_y,
                           const float *in_scale, const float *res_g, const float *res_y,
-                          const float *out_mask_y, const float *out_scale, void *stream);
+                          const float *out_mask_y, const float *out_scale, void *split_ws,
+                          void *stream);
 int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float *gy,
                           float *gw, void *ws, const float *mask_y, const float *in_scale,
                           const float *out_row_scale, void *stream);
@@ -197,7 +205,8 @@ int mrcnn_filter_flip_transpose(const float *w, float *wT, int K, int R, int S, 
 int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, const float *wT,
                           float *gx, int epi_flags, const float *mask_y,
                           const float *in_scale, const float *res_g, const float *res_y,
-                          const float *out_mask_y, const float *out_scale, void *stream);
+                          const float *out_mask_y, const float *out_scale, void *split_ws,
+                          void *stream);
 /* Stem: conv1 7x7/2 pad 3 with bias of chainer ResNet50Layers (SURVEY.md A.1;
  * models/resnet_extractor.py:65-67) fused with bn1-as-affine and ReLU.  x4 is
  * the image padded to 4 channels (N,H,W,4); w784 is the filter laid out

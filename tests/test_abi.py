@@ -54,7 +54,8 @@ def test_argument_validation_without_device(lib):
     assert rc != 0 and b'sampling_ratio' in lib.mrcnn_last_error()
     from chainer_mask_rcnn_amd._lib import ConvDesc
     d = ConvDesc(1, 8, 8, 6, 8, 3, 3, 1, 1, 8, 8)   # C=6 not a multiple of 4
-    rc = lib.mrcnn_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
+    rc = lib.mrcnn_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None,
+                              None)
     assert rc != 0 and b'multiples of 4' in lib.mrcnn_last_error()
 
 

@@ -268,3 +268,44 @@ def test_fused_stage_matches_bottleneck_chain(dev, shape, chans, stride):
     # the stage input is not masked by the stage (its ReLU belongs to the producer): a
     # negative input pixel still receives gradient
     assert (gxb[x <= 0].abs() > 0).any()
+
+
+@pytest.mark.parametrize('case', [
+    # N, C, H, W, K, k: small-M problems whose 64x64 tile count is not a multiple of 256, so
+    # the leftover rows run split along K with the slab-sum epilogue kernel
+    (2, 256, 51, 84, 256, 3),      # res4 3x3: 536 tiles -> 512 + 24 leftover, 10 splits
+    (2, 1024, 51, 84, 256, 1),     # res4 1x1 1024->256
+    (2, 128, 101, 167, 128, 3),    # res3 3x3: 1056 tiles
+    (1, 64, 67, 131, 64, 1),       # only 2 K slices: no split (too shallow)
+])
+def test_small_m_split_k_leftover_rows(dev, case):
+    N, C, H, W, K, k = case
+    rng = np.random.RandomState(sum(case))
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((K, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    shift = rng.standard_normal(K).astype(np.float32)
+    res = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    xt, wt, rt = _t(x, dev, True), _t(Wt, dev, True), _t(res, dev, True)
+    y = F.conv2d(xt, wt, None, 1, k // 2, scale=_t(scale, dev), shift=_t(shift, dev),
+                 residual=rt, relu=True)
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wr = torch.tensor(Wt, dtype=torch.float64, requires_grad=True)
+    rr = torch.tensor(res, dtype=torch.float64, requires_grad=True)
+    pre = (torch.nn.functional.conv2d(xr, wr, padding=k // 2)
+           * torch.tensor(scale, dtype=torch.float64)[None, :, None, None]
+           + torch.tensor(shift, dtype=torch.float64)[None, :, None, None] + rr)
+    yr = torch.relu(pre)
+    _close(y.detach().cpu().numpy(), yr.detach().numpy())
+    gy = rng.standard_normal(yr.shape).astype(np.float32)
+    y.backward(_t(gy, dev))
+    # the ReLU mask of the fp32 result (an fp64 reference flips elements within rounding of 0)
+    mask = (y.detach().cpu() > 0).double()
+    pre.backward(torch.tensor(gy, dtype=torch.float64) * mask)
+    _close(xt.grad.cpu().numpy(), xr.grad.numpy())
+    _close(wt.grad.cpu().numpy(), wr.grad.numpy())
+    _close(rt.grad.cpu().numpy(), rr.grad.numpy())
+    # run-to-run reproducible (slabs are summed in a fixed order)
+    y2 = F.conv2d(xt, wt, None, 1, k // 2, scale=_t(scale, dev), shift=_t(shift, dev),
+                  residual=rt, relu=True)
+    assert torch.equal(y.detach(), y2.detach())

@@ -3,7 +3,7 @@ import sys, os, ctypes
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chainer_mask_rcnn_amd import _lib
-from chainer_mask_rcnn_amd.functions.conv import make_desc, ctx_desc
+from chainer_mask_rcnn_amd.functions.conv import make_desc, ctx_desc, split_ws
 from chainer_mask_rcnn_amd.functions._layout import empty_nhwc
 
 dev = torch.device('cuda:0')
@@ -61,8 +61,9 @@ def main():
         ws = _lib.workspace(lib.mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)), dev, 'wgrad')
         sp = _lib.stream_ptr()
         flop = 2.0 * d.N * d.P * d.Q * K * C * k * k
+        sw = _lib.ptr(split_ws(dev)) if not os.environ.get('BENCH_NOSPLIT') else None
         f = lambda: _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(w), None, None,
-                              None, None, _lib.ptr(y), 0, sp)
+                              None, None, _lib.ptr(y), 0, sw, sp)
         g = lambda: _lib.call('mrcnn_conv2d_dgrad', ctx_desc(d), _lib.ptr(gy), _lib.ptr(w),
                               _lib.ptr(gx), 0, sp)
         h = lambda: _lib.call('mrcnn_conv2d_wgrad', ctx_desc(d), _lib.ptr(x), _lib.ptr(gy),
@@ -71,7 +72,7 @@ def main():
             ymask = torch.randn((d.N, d.P, d.Q, d.K), device=dev).permute(0, 3, 1, 2)
             sc = torch.rand((d.K,), device=dev) + 0.5
             g = lambda: _lib.call('mrcnn_conv2d_dgrad_ex', ctx_desc(d), _lib.ptr(gy), _lib.ptr(w),
-                                  _lib.ptr(gx), 0, _lib.ptr(ymask), _lib.ptr(sc), None, None, None, None, sp)
+                                  _lib.ptr(gx), 0, _lib.ptr(ymask), _lib.ptr(sc), None, None, None, None, sw, sp)
             h = lambda: _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(gy),
                                   _lib.ptr(gw), _lib.ptr(ws), _lib.ptr(ymask), _lib.ptr(sc), None, sp)
         tf, tg, th = timeit(f), timeit(g), timeit(h)
@@ -87,13 +88,13 @@ def main():
             if os.environ.get('BENCH_MASK'):   # consumer-side mask staging
                 t = lambda: _lib.call('mrcnn_conv2d_dgrad_wt', ctx_desc(d), _lib.ptr(gy), _lib.ptr(wT),
                                       _lib.ptr(gx), 0, _lib.ptr(ymask), _lib.ptr(sc), None, None,
-                                      None, None, sp)
+                                      None, None, sw, sp)
             else:                              # producer-side: mask + scale in the epilogue
                 xm = torch.randn((N, H, W, C), device=dev).permute(0, 3, 1, 2)
                 sc = torch.rand((C,), device=dev) + 0.5
                 t = lambda: _lib.call('mrcnn_conv2d_dgrad_wt', ctx_desc(d), _lib.ptr(gy), _lib.ptr(wT),
                                       _lib.ptr(gx), 0, None, None, None, None, _lib.ptr(xm),
-                                      _lib.ptr(sc), sp)
+                                      _lib.ptr(sc), sw, sp)
             tt = timeit(t)
         print('%-28s %5.1f|%5.2f %5.1f|%5.2f %5.1f|%5.2f %5.1f|%5.2f' % (
             name, flop / tf / 1e9, tf, flop / tg / 1e9, tg, flop / th / 1e9, th,

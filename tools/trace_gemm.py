@@ -16,7 +16,7 @@ d = make_desc(x.shape, w.shape, s, p)
 y = empty_nhwc((d.N, d.K, d.P, d.Q), dev)
 for _ in range(3):
     _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(w), None, None, None, None,
-              _lib.ptr(y), 0, _lib.stream_ptr())
+              _lib.ptr(y), 0, None, _lib.stream_ptr())
 torch.cuda.synchronize()
 n = 64 * 4 * 64 * 5
 buf = (ctypes.c_ulonglong * n)()
