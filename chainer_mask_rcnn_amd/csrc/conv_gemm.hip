@@ -775,13 +775,63 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const FixParams f)
 }
 
 template <int MODE>
+bool can_split_rows(const GemmParams &p)
+{
+    return p.split_ws && MODE != WGRAD && p.out_mode == OUT_PLAIN && !p.stem && p.N % 4 == 0 &&
+           p.ldc == p.N;
+}
+
+// rows [rows_lo, p.M) as 64x64 tiles cut along K into `splits` slabs + the ordered slab sum
+template <int MODE>
+void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_slices, hipStream_t s)
+{
+    const int rows_left = p.M - rows_lo;
+    GemmParams q = p;
+    q.C = p.split_ws;
+    q.flags = 0;
+    q.bias = q.scale = q.shift = q.residual = q.res_g = q.res_y = q.out_mask_y = nullptr;
+    q.split_len = (int)mrcnn::ceil_div(total_slices, splits);
+    splits = (int)mrcnn::ceil_div(total_slices, q.split_len);
+    q.split_stride = (int64_t)rows_left * p.N;
+    q.out_row0 = rows_lo;
+    q.c_bytes = (unsigned)(q.split_stride * 4);
+    launch_tiles<1, 1, MODE>(q, rows_lo, p.M, splits, s);
+    FixParams f = {};
+    f.ws = p.split_ws; f.C = p.C;
+    f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.residual = p.residual;
+    f.res_g = p.res_g; f.res_y = p.res_y; f.out_mask_y = p.out_mask_y;
+    f.splits = splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_lo; f.ldc = p.ldc;
+    f.flags = p.flags; f.stride = q.split_stride;
+    const int64_t n = (int64_t)rows_left * (p.N / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0,
+                       s, f);
+}
+
+// The 64x64-tile remainder of a 128x128-tile launch (rows [rows_lo, M)) runs alone on the GPU
+// after the main launch: few workgroups, each walking the whole K.  Cut along K so that about
+// two workgroups per CU share the work.
+template <int MODE>
+void launch_remainder(const GemmParams &p, int rows_lo, hipStream_t s)
+{
+    const int64_t left_tiles = mrcnn::ceil_div(p.M - rows_lo, 64) * mrcnn::ceil_div(p.N, 64);
+    const int total_slices = p.R * p.S * (int)mrcnn::ceil_div(p.Kc, BK);
+    int64_t splits = std::min<int64_t>(std::min<int64_t>(16, total_slices / 8),
+                                       mrcnn::ceil_div(512, left_tiles));
+    while (splits > 1 && (int64_t)(p.M - rows_lo) * p.N * splits * 4 > kSplitWsBytes) --splits;
+    if (!can_split_rows<MODE>(p) || splits < 2) {
+        launch_tiles<1, 1, MODE>(p, rows_lo, p.M, 1, s);
+        return;
+    }
+    launch_split_rows<MODE>(p, rows_lo, (int)splits, total_slices, s);
+}
+
+template <int MODE>
 void launch_small(const GemmParams &p, hipStream_t s)
 {
     const int64_t tm = mrcnn::ceil_div(p.M, 64), tn = mrcnn::ceil_div(p.N, 64);
     const int64_t T = tm * tn, whole = (T / 256) * 256, rem = T - whole;
     const int total_slices = p.R * p.S * (int)mrcnn::ceil_div(p.Kc, BK);
-    const bool can_split = p.split_ws && MODE != WGRAD && p.out_mode == OUT_PLAIN && !p.stem &&
-                           p.N % 4 == 0 && p.ldc == p.N && whole > 0 && whole <= 1024 && rem > 0 &&
+    const bool can_split = can_split_rows<MODE>(p) && whole > 0 && whole <= 1024 && rem > 0 &&
                            rem < 154 && total_slices >= 8;   // beyond 4 tile-times per CU the
                                                              // two extra launches cost more than
                                                              // the imbalance
@@ -796,26 +846,7 @@ void launch_small(const GemmParams &p, hipStream_t s)
         return;
     }
     launch_tiles<1, 1, MODE>(p, 0, rows_main, 1, s);
-    const int rows_left = p.M - rows_main;
-    GemmParams q = p;
-    q.C = p.split_ws;
-    q.flags = 0;
-    q.bias = q.scale = q.shift = q.residual = q.res_g = q.res_y = q.out_mask_y = nullptr;
-    q.split_len = (int)mrcnn::ceil_div(total_slices, splits);
-    splits = (int)mrcnn::ceil_div(total_slices, q.split_len);
-    q.split_stride = (int64_t)rows_left * p.N;
-    q.out_row0 = rows_main;
-    q.c_bytes = (unsigned)(q.split_stride * 4);
-    launch_tiles<1, 1, MODE>(q, rows_main, p.M, splits, s);
-    FixParams f = {};
-    f.ws = p.split_ws; f.C = p.C;
-    f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.residual = p.residual;
-    f.res_g = p.res_g; f.res_y = p.res_y; f.out_mask_y = p.out_mask_y;
-    f.splits = splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_main; f.ldc = p.ldc;
-    f.flags = p.flags; f.stride = q.split_stride;
-    const int64_t n = (int64_t)rows_left * (p.N / 4);
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0,
-                       s, f);
+    launch_split_rows<MODE>(p, rows_main, splits, total_slices, s);
 }
 
 // FWD / DGRAD launch policy.  With T 128x128 tiles and 512 resident workgroups a launch
@@ -844,7 +875,7 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
         }
         const int rows_main = (int)std::min<int64_t>(p.M, main_tiles_m * 128);
         launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
-        if (rows_main < p.M) launch_tiles<1, 1, MODE>(p, rows_main, p.M, splits, s);
+        if (rows_main < p.M) launch_remainder<MODE>(p, rows_main, s);
     }
     return mrcnn::check_launch("conv_gemm");
 }
