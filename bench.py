@@ -131,9 +131,9 @@ def pmc_traffic(kernel_name):
     if not m:
         return None
     mode = {'FWD': 0, 'DGRAD': 1, 'WGRAD': 2}[m.group(3)]
-    # forward-form launches (fwd and the transposed-filter dgrad) share one kernel symbol;
-    # the unmasked variant (<.., false, false>) is what the train step runs
-    key = 'conv_gemm_kernel<%s, %s, %d, false' % (m.group(1), m.group(2), 0 if mode == 1 else mode)
+    # profiler kinds follow the kernel symbols; the unmasked variant (<.., false, false>) is
+    # what the train step runs
+    key = 'conv_gemm_kernel<%s, %s, %d, false' % (m.group(1), m.group(2), mode)
     with open(files[-1]) as f:
         data = json.load(f)
     for k, v in data.items():
@@ -262,6 +262,9 @@ def main():
     ap.add_argument('--width', type=int, default=1333)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--profile-all', action='store_true',
+                    help='time every kernel kind (default: only the 128x128 GEMM kinds, the '
+                         'roofline candidates, so that the timed region is barely perturbed)')
     ap.add_argument('--workload', default='train', choices=['train', 'infer'],
                     help="'train' = BASELINE configs[1..3] (the headline metric); 'infer' = "
                          "configs[4]: inference-only 8x1024x1024, 1000 proposals/img")
@@ -316,7 +319,9 @@ def main():
     fence()
     lib = _lib.load()
     if not args.no_profile:
-        lib.mrcnn_profile_enable(1)
+        # mode 2: HIP events only around the 128x128 GEMM launches (the roofline candidates);
+        # every other kind just counts launches / flops / bytes
+        lib.mrcnn_profile_enable(1 if args.profile_all else 2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -336,6 +341,8 @@ def main():
         value = args.steps * global_batch / elapsed
         roofline = None
         gemm_gflop = sum(v['flops'] for k, v in prof.items() if k.startswith('conv_gemm')) / 1e9
+        timed = {k: v for k, v in prof.items() if v['total_ms'] > 0}
+        gemm_all_timed = all(v['total_ms'] > 0 for k, v in prof.items() if k.startswith('conv_gemm'))
         gemm_ms = sum(v['total_ms'] for k, v in prof.items() if k.startswith('conv_gemm'))
         if prof:
             conv = {k: v for k, v in prof.items() if k.startswith('conv_gemm')}
@@ -353,7 +360,7 @@ def main():
                                              if v['flops'] else None,
                                              gbs=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1),
                                              launches_per_step=v['launches'] / args.steps)
-                                     for k, v in prof.items()})
+                                     for k, v in timed.items()})
         out = dict(
             metric='images/sec train step, ResNet50-C4 Mask R-CNN, COCO 800x1333'
             if args.layers == 50 else 'images/sec train step, ResNet101-C4 Mask R-CNN, COCO 800x1333',
@@ -372,7 +379,8 @@ def main():
                         # RoIs only: identical loss and gradients)
                         executed_gemm_gflop_per_image=round(gemm_gflop / args.steps / args.batch, 1)
                         if prof else None,
-                        gemm_tflops=round(gemm_gflop / gemm_ms, 2) if prof else None),
+                        gemm_tflops=round(gemm_gflop / gemm_ms, 2) if prof and gemm_all_timed
+                        else None),
             roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -47,13 +47,13 @@ enum ProfKind {
     PROF_CONV_WGRAD_128, PROF_CONV_WGRAD_64, PROF_ROI_ALIGN_FWD, PROF_ROI_ALIGN_BWD,
     PROF_NMS_MASK, PROF_NMS_SCAN, PROF_TOPK, PROF_SGD, PROF_ELEMENTWISE, PROF_NUM_KINDS
 };
-bool prof_enabled();
+bool prof_enabled(int kind);
 void prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void prof_end(hipStream_t s);
 struct ProfScope {
     hipStream_t s_;
     bool on_;
-    ProfScope(int kind, double flops, double bytes, hipStream_t s) : s_(s), on_(prof_enabled())
+    ProfScope(int kind, double flops, double bytes, hipStream_t s) : s_(s), on_(prof_enabled(kind))
     {
         if (on_) prof_begin(kind, flops, bytes, s);
     }

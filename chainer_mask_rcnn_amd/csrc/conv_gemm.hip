@@ -118,7 +118,6 @@ struct GemmParams {
     //                   gradient is produced (then that conv needs no mask staging at all)
     // WGRAD epilogue: gw[k, :] *= scale[k]
     const float *res_g, *res_y, *out_mask_y;
-    int prof_kind;       // host only: profiler bucket of the 128x128 launch
     float *split_ws;     // host only: caller's split-K workspace (kSplitWsBytes) or NULL
     unsigned a_bytes, b_bytes, c_bytes;  // buffer extents (bytes) of A (and mask_y), B, C
 };
@@ -726,7 +725,11 @@ void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
     const double kdepth = (double)p.R * p.S * (p.stem ? 21.0 : (double)p.Kc);
     const double flops = 2.0 * rows * p.N * kdepth;
     const double bytes = 4.0 * ((double)rows * p.N + (double)rows * p.Kc + (double)p.N * kdepth);
-    mrcnn::ProfScope prof(p.prof_kind + (TM == 2 ? 0 : 1), flops, bytes, s);
+    // profiler buckets follow the kernel SYMBOL (what rocprofv3 reports): the forward-form
+    // instantiation runs forward convolutions and the transposed-filter dgrads alike
+    mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
+                              (TM == 2 ? 0 : 1),
+                          flops, bytes, s);
     launch_kernel<TM, TN, MODE>(p, blocks, splits, s);
 }
 
@@ -959,7 +962,7 @@ extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const 
     p.gp = d->P; p.gq = d->Q; p.sh = d->H; p.sw = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
     p.lda = d->C; p.ldb = d->R * d->S * d->C; p.ldc = d->K;
-    p.flags = epi_flags; p.out_mode = OUT_PLAIN; p.prof_kind = mrcnn::PROF_CONV_FWD_128;
+    p.flags = epi_flags; p.out_mode = OUT_PLAIN;
     p.split_ws = (float *)split_ws;
     if (int rc = set_extents(p, (int64_t)d->N * d->H * d->W * d->C, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->P * d->Q * d->K))
@@ -984,7 +987,7 @@ extern "C" int mrcnn_conv_stem_fwd(const float *x4, const float *w784, const flo
     p.gp = P; p.gq = Q; p.sh = H; p.sw = W;
     p.R = 7; p.S = 1; p.stride = 2; p.pad = 3;
     p.lda = 4; p.ldb = 7 * 32; p.ldc = K;
-    p.flags = epi_flags; p.out_mode = OUT_PLAIN; p.stem = 1; p.prof_kind = mrcnn::PROF_CONV_FWD_128;
+    p.flags = epi_flags; p.out_mode = OUT_PLAIN; p.stem = 1;
     if (int rc = set_extents(p, (int64_t)N * H * W * 4, (int64_t)K * 7 * 32, (int64_t)N * P * Q * K))
         return rc;
     return launch<FWD>(p, 1, mrcnn::as_stream(stream));
@@ -1025,7 +1028,7 @@ extern "C" int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, 
     p.R = d->R; p.S = d->S; p.pad = d->pad;
     p.lda = d->K; p.ldb = d->R * d->S * d->C; p.ldc = d->C;
     p.flags = epi_flags | (out_scale ? MRCNN_EPI_AFFINE : 0);
-    p.prof_kind = mrcnn::PROF_CONV_DGRAD_128;
+   
     p.split_ws = (float *)split_ws;
     if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->H * d->W * d->C))
@@ -1098,7 +1101,7 @@ extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, 
     p.A = gy; p.B = wT; p.C = gx;
     p.mask_y = mask_y; p.in_scale = in_scale; p.res_g = res_g; p.res_y = res_y;
     p.out_mask_y = out_mask_y; p.scale = out_scale;
-    p.prof_kind = mrcnn::PROF_CONV_DGRAD_128;
+   
     p.split_ws = (float *)split_ws;
     p.M = d->N * d->H * d->W; p.N = d->C; p.Kc = d->K;
     p.gp = d->H; p.gq = d->W; p.sh = d->P; p.sw = d->Q;
@@ -1202,7 +1205,7 @@ extern "C" int mrcnn_deconv2x2s2_fwd(const float *x, const float *w, const float
     p.gp = H; p.gq = W; p.sh = H; p.sw = W;
     p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.lda = C; p.ldb = 4 * K; p.ldc = K;
-    p.flags = epi_flags; p.out_mode = OUT_DECONV; p.ko = K; p.prof_kind = mrcnn::PROF_CONV_FWD_128;
+    p.flags = epi_flags; p.out_mode = OUT_DECONV; p.ko = K;
     if (int rc = set_extents(p, (int64_t)N * H * W * C, (int64_t)C * 4 * K, (int64_t)N * 4 * H * W * K))
         return rc;
     return launch<DGRAD>(p, 1, mrcnn::as_stream(stream));

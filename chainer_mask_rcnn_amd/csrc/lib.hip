@@ -21,7 +21,7 @@ void set_error(const char *fmt, ...)
 namespace {
 struct ProfRec { hipEvent_t start, stop; int kind; double flops, bytes; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+int g_prof_mode = 0;   // 0 off, 1 every kind, 2 only the 128x128 GEMM kinds
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_event_pool;
 hipEvent_t get_event()
@@ -37,25 +37,33 @@ hipEvent_t get_event()
 }
 }  // namespace
 
-bool prof_enabled() { return g_prof_on; }
+bool prof_timed(int kind)
+{
+    if (g_prof_mode == 1) return true;
+    return g_prof_mode == 2 && (kind == PROF_CONV_FWD_128 || kind == PROF_CONV_DGRAD_128 ||
+                                kind == PROF_CONV_WGRAD_128);
+}
+bool prof_enabled(int) { return g_prof_mode != 0; }
 
 void prof_begin(int kind, double flops, double bytes, hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
-    r.start = get_event();
-    r.stop = get_event();
+    const bool timed = prof_timed(kind);   // untimed kinds still count launches / flops / bytes
+    r.start = timed ? get_event() : nullptr;
+    r.stop = timed ? get_event() : nullptr;
     r.kind = kind;
     r.flops = flops;
     r.bytes = bytes;
-    (void)hipEventRecord(r.start, s);
+    if (timed) (void)hipEventRecord(r.start, s);
     g_prof_recs.push_back(r);
 }
 
 void prof_end(hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_recs.empty()) (void)hipEventRecord(g_prof_recs.back().stop, s);
+    if (!g_prof_recs.empty() && g_prof_recs.back().stop)
+        (void)hipEventRecord(g_prof_recs.back().stop, s);
 }
 }  // namespace mrcnn
 
@@ -69,11 +77,11 @@ extern "C" int mrcnn_profile_enable(int on)
 {
     std::lock_guard<std::mutex> lk(mrcnn::g_prof_mu);
     for (auto &r : mrcnn::g_prof_recs) {
-        mrcnn::g_event_pool.push_back(r.start);
-        mrcnn::g_event_pool.push_back(r.stop);
+        if (r.start) mrcnn::g_event_pool.push_back(r.start);
+        if (r.stop) mrcnn::g_event_pool.push_back(r.stop);
     }
     mrcnn::g_prof_recs.clear();
-    mrcnn::g_prof_on = on != 0;
+    mrcnn::g_prof_mode = on;
     return 0;
 }
 
@@ -95,7 +103,7 @@ extern "C" int mrcnn_profile_summary(int kind, double *total_ms, double *total_f
     for (auto &r : mrcnn::g_prof_recs) {
         if (r.kind != kind) continue;
         float t = 0.f;
-        hipError_t e = hipEventElapsedTime(&t, r.start, r.stop);
+        hipError_t e = r.start ? hipEventElapsedTime(&t, r.start, r.stop) : hipSuccess;
         if (e != hipSuccess) {
             mrcnn::set_error("profile_summary: %s", hipGetErrorString(e));
             return 1;

@@ -40,8 +40,11 @@ int mrcnn_device_info(int *n_cu, char *name, int name_len);
 
 /* Kernel timer: HIP events recorded on the launch stream around every hot kernel while
  * enabled.  bench.py uses it to report roofline numbers (average launch duration and
- * algorithmic flops / bytes per kernel kind).  mrcnn_profile_enable(1) clears the
- * records; mrcnn_profile_summary sums them (synchronise the stream first). */
+ * algorithmic flops / bytes per kernel kind; kinds follow the kernel symbols rocprofv3
+ * reports).  mrcnn_profile_enable(mode) clears the records; mode 0 = off, 1 = every kind,
+ * 2 = only the 128x128 conv-GEMM kinds (the roofline candidates: ~90 instead of ~500 event
+ * pairs per train step, so the timed region is barely perturbed);
+ * mrcnn_profile_summary sums the records (synchronise the stream first). */
 int mrcnn_profile_enable(int on);
 int mrcnn_profile_num_kinds(void);
 const char *mrcnn_profile_kind_name(int kind);

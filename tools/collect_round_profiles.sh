@@ -4,6 +4,7 @@
 TAG=$1
 R=$GRAFT_REPO_ROOT
 python $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
+python $R/bench.py --profile-all --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_allkinds.json 2>> $R/gpurun_out/${TAG}_bench.err
 python $R/bench.py --workload infer --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_bench_infer.json 2>> $R/gpurun_out/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -o ${TAG} -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats.log 2>&1
