@@ -90,6 +90,17 @@ class MaskRCNN(torch.nn.Module):
         return self._suppress_finish(*self._suppress_queue(cls_bbox, prob))
 
     def _to_bboxes(self, roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales):
+        queued = self._queue_detections(roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales)
+        bboxes, labels, scores = [], [], []
+        for q in queued:
+            bbox, label, score = self._finish_detections(q)
+            bboxes.append(bbox)
+            labels.append(label)
+            scores.append(score)
+        return bboxes, labels, scores
+
+    def _queue_detections(self, roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales):
+        """Device half of ``_to_bboxes`` for every image, queued without synchronising."""
         probs = F.softmax(roi_scores.detach())
         roi_cls_locs = roi_cls_locs.detach()
         if roi_cls_locs.stride(1) != 1:
@@ -116,27 +127,40 @@ class MaskRCNN(torch.nn.Module):
                       _lib.ptr(cls_bbox), R, self.n_class, float(scales[index]), mean, std,
                       float(sizes[index][0]), float(sizes[index][1]), _lib.stream_ptr())
             queued.append(self._suppress_queue(cls_bbox, prob))
+        return queued
 
-        bboxes, labels, scores = [], [], []
-        for q in queued:
-            bbox, label, score = self._suppress_finish(*q)
+    def _finish_detections(self, q):
+        """Host half of ``_to_bboxes`` for one image (:247-260)."""
+        bbox, label, score = self._suppress_finish(*q)
 
-            bbox_int = np.round(bbox).astype(np.int32)
-            bbox_sizes = ((bbox_int[:, 2] - bbox_int[:, 0]) * (bbox_int[:, 3] - bbox_int[:, 1]))
-            ok = bbox_sizes > 0
+        bbox_int = np.round(bbox).astype(np.int32)
+        bbox_sizes = ((bbox_int[:, 2] - bbox_int[:, 0]) * (bbox_int[:, 3] - bbox_int[:, 1]))
+        ok = bbox_sizes > 0
+        bbox, label, score = bbox[ok], label[ok], score[ok]
+
+        if self._detections_per_im > 0:
+            # literal restatement of models/mask_rcnn.py:255-260 (an argsort
+            # permutation compared with a rank threshold; SURVEY.md Appendix B)
+            indices = np.argsort(score, kind='stable')
+            ok = indices >= (len(indices) - self._detections_per_im)
             bbox, label, score = bbox[ok], label[ok], score[ok]
+        return bbox, label, score
 
-            if self._detections_per_im > 0:
-                # literal restatement of models/mask_rcnn.py:255-260 (an argsort
-                # permutation compared with a rank threshold)
-                indices = np.argsort(score, kind='stable')
-                ok = indices >= (len(indices) - self._detections_per_im)
-                bbox, label, score = bbox[ok], label[ok], score[ok]
-
-            bboxes.append(bbox)
-            labels.append(label)
-            scores.append(score)
-        return bboxes, labels, scores
+    def _roi_masks_group(self, h, bboxes, image_ids, scales):
+        """Mask-head pass (:279-289) for the detections of the images ``image_ids`` (one head
+        launch for the group); returns one device tensor (D_i, n_fg, M, M) per image."""
+        n_fg_class, mask_size = self.n_class - 1, self.head.mask_size
+        counts = [len(b) for b in bboxes]
+        if sum(counts) == 0:
+            return [torch.zeros((0, n_fg_class, mask_size, mask_size), device=h.device)
+                    for _ in bboxes]
+        rois = np.concatenate([b * np.float32(scales[i]) for b, i in zip(bboxes, image_ids)], axis=0)
+        idx = np.concatenate([np.full((c,), i, dtype=np.int32) for c, i in zip(counts, image_ids)])
+        with torch.no_grad():
+            _, _, roi_masks = self.head(h, torch.tensor(rois, dtype=torch.float32, device=h.device),
+                                        torch.tensor(idx, device=h.device), pred_bbox=False)
+        bounds = np.concatenate([[0], np.cumsum(counts)])
+        return [roi_masks[int(bounds[k]):int(bounds[k + 1])] for k in range(len(bboxes))]
 
     def _to_roi_masks(self, h, bboxes, roi_indices, scales, to_host=True):
         batch_size = h.shape[0]
@@ -253,11 +277,26 @@ class MaskRCNN(torch.nn.Module):
                     scs.append(s_i)
                 roi_cls_locs = torch.cat(locs, dim=0)
                 roi_scores = torch.cat(scs, dim=0)
-            bboxes, labels, scores = self._to_bboxes(
-                roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales)
-            roi_indices = np.concatenate(
-                [np.full((len(b),), i, dtype=np.int32) for i, b in enumerate(bboxes)], axis=0)
-            roi_masks = self._to_roi_masks(h, bboxes, roi_indices, scales, to_host=masks_to_host)
+            # Detections: every image's device work is queued first; the host halves then run
+            # group by group and each group's mask-head pass is launched as soon as its
+            # boxes are final, so the GPU computes masks while the host finishes the next
+            # group (rows of the head are independent: same values as one pass over all).
+            queued = self._queue_detections(roi_cls_locs, roi_scores, rois, roi_indices,
+                                            sizes, scales)
+            n_img = len(queued)
+            n_groups = 2 if n_img >= 4 else 1
+            per = -(-n_img // n_groups)
+            bboxes, labels, scores, roi_masks = [], [], [], []
+            for g0 in range(0, n_img, per):
+                ids = list(range(g0, min(g0 + per, n_img)))
+                for i in ids:
+                    b, l, s = self._finish_detections(queued[i])
+                    bboxes.append(b)
+                    labels.append(l)
+                    scores.append(s)
+                roi_masks += self._roi_masks_group(h, [bboxes[i] for i in ids], ids, scales)
+            if masks_to_host:
+                roi_masks = [m.cpu().numpy() for m in roi_masks]
         finally:
             self.train(was_training)
         return bboxes, roi_masks, labels, scores
