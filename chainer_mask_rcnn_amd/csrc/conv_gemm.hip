@@ -681,7 +681,19 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, i
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
          i += (int64_t)gridDim.x * blockDim.x) {
         float4 a = reinterpret_cast<const float4 *>(ws)[i];
-        for (int s = 1; s < splits; ++s) {
+        int s = 1;
+        // four slab loads in flight per step; the additions keep the slab order
+        for (; s + 4 <= splits; s += 4) {
+            const float4 v0 = reinterpret_cast<const float4 *>(ws + (s + 0) * stride)[i];
+            const float4 v1 = reinterpret_cast<const float4 *>(ws + (s + 1) * stride)[i];
+            const float4 v2 = reinterpret_cast<const float4 *>(ws + (s + 2) * stride)[i];
+            const float4 v3 = reinterpret_cast<const float4 *>(ws + (s + 3) * stride)[i];
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+            a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+            a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+        }
+        for (; s < splits; ++s) {
             const float4 v = reinterpret_cast<const float4 *>(ws + s * stride)[i];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
@@ -1159,8 +1171,7 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     else
         launch_kernel<1, 1, WGRAD>(p, tiles, splits, s);
     if (splits > 1) {
-        int64_t blocks = mrcnn::ceil_div(gwsz / 4, 256);
-        if (blocks > 4096) blocks = 4096;
+        const int64_t blocks = mrcnn::ceil_div(gwsz / 4, 256);   // one float4 per thread
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            (const float *)ws, splits, gwsz, gwsz, gw);
     }
