@@ -62,6 +62,7 @@ SIGNATURES = {
     'mrcnn_conv2d_dgrad_ex': (c_int, [_DP, c_vp, c_vp, c_vp, c_int] + [c_vp] * 8),
     'mrcnn_conv2d_wgrad_ex': (c_int, [_DP] + [c_vp] * 8),
     'mrcnn_filter_flip_transpose': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'mrcnn_filter_flip_transpose_batched': (c_int, [c_int] + [c_vp] * 8),
     'mrcnn_conv2d_dgrad_wt': (c_int, [_DP, c_vp, c_vp, c_vp, c_int] + [c_vp] * 8),
     'mrcnn_conv_stem_fwd': (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp]),
     'mrcnn_deconv2x2s2_fwd': (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),

@@ -1083,7 +1083,77 @@ __global__ void filter_flip_transpose_kernel(const float *__restrict__ w, float 
         if (c < C && k < K) wT[((int64_t)c * RS + (RS - 1 - rs)) * K + k] = tile[tx][j];
     }
 }
+
+// up to 32 filters per launch: a ResNet stage needs ~14 of these five-microsecond transposes,
+// launch latency dominates them
+constexpr int kFlipBatch = 32;
+struct FlipBatch {
+    const float *w[kFlipBatch];
+    float *wT[kFlipBatch];
+    const float *scale[kFlipBatch];
+    int K[kFlipBatch], RS[kFlipBatch], C[kFlipBatch];
+    int first_block[kFlipBatch + 1];
+    int n;
+};
+
+__global__ void filter_flip_transpose_batched_kernel(const FlipBatch b)
+{
+    __shared__ float tile[32][33];
+    int l = 0;
+    while (l + 1 < b.n && (int)blockIdx.x >= b.first_block[l + 1]) ++l;
+    const int K = b.K[l], RS = b.RS[l], C = b.C[l];
+    int blk = blockIdx.x - b.first_block[l];
+    const int ncb = (C + 31) / 32, nkb = (K + 31) / 32;
+    const int cb = blk % ncb;
+    blk /= ncb;
+    const int kb = blk % nkb, rs = blk / nkb;
+    const float *__restrict__ w = b.w[l];
+    float *__restrict__ wT = b.wT[l];
+    const float *__restrict__ row_scale = b.scale[l];
+    const int k0 = kb * 32, c0 = cb * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int k = k0 + j, c = c0 + tx;
+        tile[j][tx] = (k < K && c < C)
+                          ? w[((int64_t)k * RS + rs) * C + c] * (row_scale ? row_scale[k] : 1.f)
+                          : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, k = k0 + tx;
+        if (c < C && k < K) wT[((int64_t)c * RS + (RS - 1 - rs)) * K + k] = tile[tx][j];
+    }
+}
 }  // namespace
+
+extern "C" int mrcnn_filter_flip_transpose_batched(int n, const void *const *w, void *const *wT,
+                                                   const int *K, const int *R, const int *S,
+                                                   const int *C, const void *const *row_scale,
+                                                   void *stream)
+{
+    MRCNN_REQUIRE(n >= 0 && (n == 0 || (w && wT && K && R && S && C)),
+                  "filter_flip_transpose_batched: bad args");
+    for (int i0 = 0; i0 < n; i0 += kFlipBatch) {
+        FlipBatch b = {};
+        b.n = std::min(kFlipBatch, n - i0);
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const int j = i0 + i;
+            MRCNN_REQUIRE(w[j] && wT[j] && K[j] > 0 && R[j] > 0 && S[j] > 0 && C[j] > 0,
+                          "filter_flip_transpose_batched: bad entry %d", j);
+            b.w[i] = (const float *)w[j];
+            b.wT[i] = (float *)wT[j];
+            b.scale[i] = row_scale ? (const float *)row_scale[j] : nullptr;
+            b.K[i] = K[j]; b.RS[i] = R[j] * S[j]; b.C[i] = C[j];
+            b.first_block[i] = blocks;
+            blocks += ((C[j] + 31) / 32) * ((K[j] + 31) / 32) * R[j] * S[j];
+        }
+        b.first_block[b.n] = blocks;
+        hipLaunchKernelGGL(filter_flip_transpose_batched_kernel, dim3(blocks), dim3(256), 0,
+                           mrcnn::as_stream(stream), b);
+    }
+    return mrcnn::check_launch("filter_flip_transpose_batched");
+}
 
 extern "C" int mrcnn_filter_flip_transpose(const float *w, float *wT, int K, int R, int S, int C,
                                            const float *row_scale, void *stream)

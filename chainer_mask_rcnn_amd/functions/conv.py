@@ -270,6 +270,42 @@ def _flip_transpose(Wc, d, row_scale, out):
     return out
 
 
+def _stage_transposes(blocks, scales, device):
+    """Flipped / transposed filters of every stride-1 convolution of a stage, built by ONE
+    launch into one buffer.  ``blocks``: ((d1,d2,d3,d4), (W1,W2,W3,W4), _) per bottleneck,
+    ``scales``: (s3, s4) per bottleneck (folded into conv3 / conv4).  Returns a dict
+    {'1','2','3','4'} -> flat tensor per block."""
+    import ctypes
+    jobs = []
+    for bi, ((d1, d2, d3, d4), (W1, W2, W3, W4), _) in enumerate(blocks):
+        s3, s4 = scales[bi]
+        for key, W, d, sc in (('1', W1, d1, None), ('2', W2, d2, None), ('3', W3, d3, s3),
+                              ('4', W4, d4, s4)):
+            if W is not None and _uses_transposed_dgrad(d):
+                jobs.append((bi, key, nhwc(W), d, sc))
+    out = [dict() for _ in blocks]
+    if not jobs:
+        return out
+    total = sum(j[2].numel() for j in jobs)
+    buf = torch.empty((total,), dtype=torch.float32, device=device)
+    n = len(jobs)
+    vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+    w, wT, sc = vp(), vp(), vp()
+    K, R, S, C = ci(), ci(), ci(), ci()
+    off = 0
+    keep = []
+    for i, (bi, key, Wc, d, scale) in enumerate(jobs):
+        t = buf[off:off + Wc.numel()]
+        off += Wc.numel()
+        out[bi][key] = t
+        keep.append(Wc)
+        w[i], wT[i] = Wc.data_ptr(), t.data_ptr()
+        sc[i] = scale.data_ptr() if scale is not None else None
+        K[i], R[i], S[i], C[i] = d.K, d.R, d.S, d.C
+    _lib.call('mrcnn_filter_flip_transpose_batched', n, w, wT, K, R, S, C, sc, _lib.stream_ptr())
+    return out
+
+
 def _uses_transposed_dgrad(d):
     return USE_TRANSPOSED_DGRAD and d.stride == 1 and d.R == d.S
 
@@ -477,18 +513,10 @@ class _StageFn(torch.autograd.Function):
             dev = x.device
             side, main = wgrad_stream(dev), torch.cuda.current_stream(dev)
             side.wait_stream(main)          # the previous step's SGD update of the weights
-            ctx.wT = []
             with torch.cuda.stream(side):
-                for (d1, d2, d3, d4), (W1, W2, W3, W4), p0 in blocks:
-                    s3 = params[p0 + 7]
-                    s4 = params[p0 + 10] if W4 is not None else None
-                    t = {}
-                    for key, W, d, sc in (('1', W1, d1, None), ('2', W2, d2, None),
-                                          ('3', W3, d3, s3), ('4', W4, d4, s4)):
-                        if W is not None and _uses_transposed_dgrad(d):
-                            t[key] = _flip_transpose(
-                                nhwc(W), d, sc, torch.empty((W.numel(),), dtype=torch.float32, device=dev))
-                    ctx.wT.append(t)
+                ctx.wT = _stage_transposes(
+                    blocks, [(params[p0 + 7], params[p0 + 10] if W4 is not None else None)
+                             for _, (_, _, _, W4), p0 in blocks], dev)
                 ctx.wT_ready = torch.cuda.Event()
                 ctx.wT_ready.record(side)
         return h
@@ -519,12 +547,16 @@ class _StageFn(torch.autograd.Function):
             for t in ctx.wT:
                 for buf in t.values():
                     buf.record_stream(main)
+            stage_wT = ctx.wT
+        else:
+            # all the stage's filter transposes in one launch
+            stage_wT = _stage_transposes(ctx.blocks, [(a[6], a[7]) for a in acts], gy.device)
         # gm: gradient w.r.t. the block output, already through that output's ReLU
         gm = epilogue_bwd(gy, acts[-1][3], None)
         for i in range(len(acts) - 1, -1, -1):
             x, h1, h2, y, s1, s2, s3, s4 = acts[i]
             (d1, d2, d3, d4), (W1, W2, W3, W4), p0 = ctx.blocks[i]
-            wT = ctx.wT[i] if ctx.wT is not None else {}
+            wT = stage_wT[i]
             base = 3 + p0                      # index of W1 among the forward inputs
             first = i == 0
             # what the gradient leaving this block must be masked with: the previous block's

@@ -205,6 +205,11 @@ int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float 
  * Same extra arguments as _ex. */
 int mrcnn_filter_flip_transpose(const float *w, float *wT, int K, int R, int S, int C,
                                 const float *row_scale, void *stream);
+/* The same for n filters in one launch (host arrays of n device pointers / sizes; row_scale
+ * or its entries may be NULL): a ResNet stage's backward needs ~14 of them. */
+int mrcnn_filter_flip_transpose_batched(int n, const void *const *w, void *const *wT,
+                                        const int *K, const int *R, const int *S, const int *C,
+                                        const void *const *row_scale, void *stream);
 int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, const float *wT,
                           float *gx, int epi_flags, const float *mask_y,
                           const float *in_scale, const float *res_g, const float *res_y,
