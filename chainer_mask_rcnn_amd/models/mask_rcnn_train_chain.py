@@ -46,6 +46,26 @@ def _pool():
     return _POOL
 
 
+_NP_OF = {torch.float32: np.float32, torch.int32: np.int32, torch.int64: np.int64}
+
+
+def _upload_many(arrays, dtypes, dev):
+    """Several host arrays -> device tensors with ONE copy: the arrays are packed (64-byte
+    aligned) into one byte buffer, uploaded through ``_upload`` and returned as typed views."""
+    parts, spans, off = [], [], 0
+    for a, dt in zip(arrays, dtypes):
+        a = np.ascontiguousarray(a, dtype=_NP_OF[dt])
+        pad = (-off) % 64
+        if pad:
+            parts.append(np.zeros(pad, np.uint8))
+            off += pad
+        parts.append(a.reshape(-1).view(np.uint8))
+        spans.append((off, a.nbytes, a.shape, dt))
+        off += a.nbytes
+    flat = _upload(np.concatenate(parts), torch.uint8, dev)
+    return [flat[o:o + n].view(dt).reshape(shape) for o, n, shape, dt in spans]
+
+
 class MaskRCNNTrainChain(torch.nn.Module):
 
     def __init__(self, mask_rcnn, rpn_sigma=3., roi_sigma=1.,
@@ -112,16 +132,18 @@ class MaskRCNNTrainChain(torch.nn.Module):
                 sample_roi, gt_roi_loc, gt_roi_label, gt_roi_mask = \
                     ptc(roi, bbox, label, to_np(mask))
                 gt_roi_masks.append(gt_roi_mask)
+            mark('ptc.sample')
             sample_rois.append(sample_roi)
             sample_roi_indices.append(np.full((len(sample_roi),), batch_index, dtype=np.int32))
             gt_roi_locs.append(gt_roi_loc)
             gt_roi_labels.append(gt_roi_label)
         up = lambda parts, dt: _upload(np.concatenate(parts, axis=0), dt, dev)
         gt_roi_labels_h = np.concatenate(gt_roi_labels, axis=0)
-        sample_rois = up(sample_rois, torch.float32)
-        sample_roi_indices = up(sample_roi_indices, torch.int32)
-        gt_roi_locs = up(gt_roi_locs, torch.float32)
-        gt_roi_labels = up(gt_roi_labels, torch.int32)
+        fg_rows = np.flatnonzero(gt_roi_labels_h > 0) if self.mask_branch_fg_only else np.zeros(0)
+        cat = lambda parts: np.concatenate(parts, axis=0)
+        sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels, fg_rows_d = _upload_many(
+            [cat(sample_rois), cat(sample_roi_indices), cat(gt_roi_locs), gt_roi_labels_h, fg_rows],
+            [torch.float32, torch.int32, torch.float32, torch.int32, torch.int64], dev)
 
         # The reference runs the mask branch on every sampled RoI (:147-148) although
         # background rows carry all-ignored (-1) mask targets and therefore contribute
@@ -130,10 +152,8 @@ class MaskRCNNTrainChain(torch.nn.Module):
         # (same normaliser: the count of non-ignored target pixels) and identical gradients.
         mark('rois sampled')
         mask_rows = None
-        if self.mask_branch_fg_only:
-            fg_rows = np.flatnonzero(gt_roi_labels_h > 0)
-            if len(fg_rows) > 0:
-                mask_rows = torch.tensor(fg_rows, dtype=torch.int64, device=dev)
+        if self.mask_branch_fg_only and len(fg_rows) > 0:
+            mask_rows = fg_rows_d
         roi_cls_locs, roi_scores, roi_masks = self.mask_rcnn.head(
             features, sample_rois, sample_roi_indices, mask_rows=mask_rows)
 
@@ -154,8 +174,9 @@ class MaskRCNNTrainChain(torch.nn.Module):
                 gt_rpn_loc, gt_rpn_label = atc(bbox, anchor_h, img_size)
             gt_rpn_locs.append(gt_rpn_loc)
             gt_rpn_labels.append(gt_rpn_label)
-        gt_rpn_locs = up(gt_rpn_locs, torch.float32)
-        gt_rpn_labels = up(gt_rpn_labels, torch.int32)
+        gt_rpn_locs, gt_rpn_labels = _upload_many(
+            [np.concatenate(gt_rpn_locs, axis=0), np.concatenate(gt_rpn_labels, axis=0)],
+            [torch.float32, torch.int32], dev)
         mark('rpn targets')
         rpn_locs = rpn_locs.reshape(-1, 4)
         rpn_scores = rpn_scores.reshape(-1)

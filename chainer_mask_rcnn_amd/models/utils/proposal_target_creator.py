@@ -8,7 +8,7 @@ CPU, :112-115): integer/sampling work whose results depend on the *global*
 """
 import numpy as np
 
-from ...utils.bbox import bbox_iou, bbox2loc, resize_bilinear
+from ...utils.bbox import bbox_iou_t, bbox2loc, resize_bilinear
 
 
 class ProposalTargetCreator(object):
@@ -50,9 +50,9 @@ class ProposalTargetCreator(object):
         # ground-truth boxes are candidates too (:121)
         cand = np.concatenate((roi, bbox), axis=0)
         n_pos_max = np.round(self.n_sample * self.pos_ratio)
-        iou = bbox_iou(cand, bbox)
-        assigned = iou.argmax(axis=1)
-        best = iou.max(axis=1)
+        iou_t = bbox_iou_t(cand, bbox)            # (G, R): the long axis contiguous
+        assigned = iou_t.argmax(axis=0)
+        best = iou_t.max(axis=0)
         cand_label = label[assigned] + 1          # 0 is background (:129)
 
         fg = np.where(best >= self.pos_iou_thresh)[0]

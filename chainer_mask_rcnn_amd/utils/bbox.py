@@ -51,6 +51,22 @@ def bbox_iou(bbox_a, bbox_b):
     return inter / (area_a[:, None] + area_b[None, :] - inter)
 
 
+def bbox_iou_t(bbox_a, bbox_b):
+    """``bbox_iou(a, b).T`` — the (len(b), len(a)) layout keeps the long axis contiguous, which
+    is what the few-ground-truths x thousands-of-candidates calls of the target creators want
+    (same fp32 operations element by element, ~4x faster than the (A, B) broadcast)."""
+    a = np.ascontiguousarray(np.asarray(bbox_a, np.float32).T)     # (4, A)
+    b = np.asarray(bbox_b, np.float32)
+    by1, bx1, by2, bx2 = (b[:, i, None] for i in range(4))
+    tl_y, tl_x = np.maximum(a[0], by1), np.maximum(a[1], bx1)
+    br_y, br_x = np.minimum(a[2], by2), np.minimum(a[3], bx2)
+    inter = (br_y - tl_y) * (br_x - tl_x)
+    inter *= ((tl_y < br_y) & (tl_x < br_x))
+    area_a = (a[2] - a[0]) * (a[3] - a[1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (area_a[None, :] + area_b[:, None] - inter)
+
+
 def bbox2loc(src_bbox, dst_bbox):
     """Offsets/scales (dy, dx, dh, dw) that map src boxes onto dst boxes."""
     src = np.asarray(src_bbox, np.float32)
