@@ -74,6 +74,15 @@ constexpr int min_blocks(int tm, int mode, bool masked)
     if (!single_buffered(tm, mode, masked)) return MRCNN_GEMM_MINWAVES;
     return tm == 2 ? 3 : 6;
 }
+// Experiment, off by default: the last workgroup of a wgrad tile to arrive sums the split-K
+// slabs inside the GEMM kernel instead of a separate reduce launch.  Correct (tools/
+// check_wgrad_reduce.py: no stale slab under load, bit-repeatable), but the agent-scope release
+// every workgroup needs before it signals writes back its XCD's whole dirty L2 — measured
+// 55.6 vs 51.6 ms per train step, i.e. 4 ms SLOWER than the 0.67 ms reduce launches it removes.
+#ifndef MRCNN_WGRAD_INKERNEL_REDUCE
+#define MRCNN_WGRAD_INKERNEL_REDUCE 0
+#endif
+constexpr int64_t kWgradCounterBytes = 1 << 20;   // >= 4 B x tiles for any supported filter
 constexpr int KPAD = 4;  // K-contiguous LDS rows are 36 floats (conflict-free b128)
 
 // The stride-1 dgrad is also run in FWD mode: a forward convolution of gy with the flipped,
@@ -107,6 +116,10 @@ struct GemmParams {
     int split_len;       // WGRAD: pixels per split; FWD/DGRAD: K slices per split (0: no split)
     int64_t split_stride;// floats between split slabs
     int out_row0;        // FWD/DGRAD split launches: first row of the slab (subtracted)
+    // WGRAD in-kernel slab reduction: per-tile arrival counters (zeroed by the host) and the
+    // final gradient; the last workgroup of a tile to arrive sums the slabs in slab order
+    int *tile_counters;
+    float *reduce_out;
     // Fused backward of the producing conv's epilogue, applied while gy is staged
     // (DGRAD A operand / WGRAD A' operand):  g = gy * (mask_y > 0) * in_scale[k]
     const float *mask_y;   // output of the ReLU that followed the conv (same shape as gy) or NULL
@@ -672,6 +685,65 @@ conv_gemm_kernel(const GemmParams p)
             }
         }
     }
+
+#if MRCNN_WGRAD_INKERNEL_REDUCE
+    if (MODE == WGRAD && p.tile_counters != nullptr) {
+        // Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): plain stores ->
+        // barrier -> lane 0: agent-scope release, explicit vmcnt(0), relaxed agent atomic on
+        // the tile's counter; the workgroup that observes splits-1 earlier arrivals performs
+        // ONE agent-scope acquire, then everybody reads the slabs with plain loads.
+        const int nsplits = (int)gridDim.y;
+        __syncthreads();                 // every wave is done with the LDS stages: reuse a word
+        int &s_last = *reinterpret_cast<int *>(&smem_all[0][0][0]);
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int old = __hip_atomic_fetch_add(&p.tile_counters[tile], 1, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == nsplits - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                p.tile_counters[tile] = 0;       // ready for the next launch
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const __amdgpu_buffer_rsrc_t rOut = make_rsrc(p.reduce_out, p.c_bytes);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (32 * TN) + j * 32 + li;
+            const bool col_ok = col < p.N;
+            const int colc = col_ok ? col : 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    unsigned off[8];
+                    float sum[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = g * 8 + q;
+                        const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                        off[q] = (col_ok && row < p.M) ? 4u * (unsigned)(row * p.ldc + colc) : kOOB;
+                        sum[q] = 0.f;
+                    }
+                    for (int sp = 0; sp < nsplits; ++sp) {       // fixed order: deterministic
+                        const __amdgpu_buffer_rsrc_t rS =
+                            make_rsrc(p.C + (int64_t)sp * p.split_stride, p.c_bytes);
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = bload1(rS, off[q]);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) sum[q] += v[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bstore1(rOut, off[q], sum[q]);
+                }
+            }
+        }
+    }
+#endif
 }
 
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, int64_t n,
@@ -1201,7 +1273,7 @@ extern "C" int64_t mrcnn_conv2d_wgrad_workspace_bytes(const mrcnn_conv_desc *d)
 {
     if (!d) return 0;
     const int64_t gwsz = (int64_t)d->K * d->R * d->S * d->C;
-    return 64 * gwsz * 4;  // upper bound: 64 split slabs
+    return 64 * gwsz * 4 + kWgradCounterBytes;  // 64 split slabs + per-tile arrival counters
 }
 
 static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int Kout, int64_t pixels,
@@ -1233,6 +1305,13 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     p.split_stride = gwsz;
     if (int rc = set_extents(p, pixels * ldg, (int64_t)N_ * H * W * C, gwsz)) return rc;
     p.C = splits > 1 ? (float *)ws : gw;
+    const bool in_kernel = MRCNN_WGRAD_INKERNEL_REDUCE != 0 && splits > 1;
+    if (in_kernel) {
+        // counters live behind the 64 slabs of the workspace
+        p.tile_counters = (int *)((char *)ws + 64 * gwsz * 4);
+        p.reduce_out = gw;
+        MRCNN_HIP_TRY(hipMemsetAsync(p.tile_counters, 0, sizeof(int) * (size_t)tiles, s));
+    }
     mrcnn::ProfScope prof(use_big ? mrcnn::PROF_CONV_WGRAD_128 : mrcnn::PROF_CONV_WGRAD_64,
                           2.0 * p.M * p.N * (double)pixels,
                           4.0 * ((double)p.M * p.N + (double)pixels * (p.M + (double)C)), s);
@@ -1240,7 +1319,7 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
         launch_kernel<2, 2, WGRAD>(p, big, splits, s);
     else
         launch_kernel<1, 1, WGRAD>(p, tiles, splits, s);
-    if (splits > 1) {
+    if (splits > 1 && !in_kernel) {
         const int64_t blocks = mrcnn::ceil_div(gwsz / 4, 256);   // one float4 per thread
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            (const float *)ws, splits, gwsz, gwsz, gw);
@@ -1302,7 +1381,7 @@ extern "C" int mrcnn_deconv2x2s2_dgrad(const float *gy, const float *w, float *g
 
 extern "C" int64_t mrcnn_deconv2x2s2_wgrad_workspace_bytes(int N, int H, int W, int C, int K)
 {
-    return 64ll * C * 4 * K * 4;
+    return 64ll * C * 4 * K * 4 + kWgradCounterBytes;
 }
 
 extern "C" int mrcnn_deconv2x2s2_wgrad(const float *x, const float *gy, float *gw, int N, int H,
