@@ -167,3 +167,22 @@ def test_image_io_matches_reference_body_fixtures(dev, golden_dir):
     bbox, label, logits, im_h, im_w, masks = _segm_fixture(golden_dir)
     got = model._to_masks([bbox], [label], None, [torch.tensor(logits, device=dev)], [(im_h, im_w)])
     assert got[0].shape == masks.shape and (got[0] != masks).mean() < 1e-6
+
+
+def test_predict_with_no_detections(dev):
+    """Nothing above the score threshold: empty per-image results of the right types/shapes
+    (the reference returns empty arrays, mask_rcnn.py:63-65 for the masks)."""
+    torch.manual_seed(0)
+    rng = np.random.RandomState(9)
+    model = cmr.models.MaskRCNNResNet(50, n_fg_class=80, min_size=128, max_size=192,
+                                      anchor_scales=(2, 4, 8, 16, 32), roi_size=14,
+                                      proposal_creator_params=dict(min_size=0, n_test_pre_nms=200,
+                                                                   n_test_post_nms=30)).to(dev)
+    model.score_thresh = 1.1
+    imgs = [rng.randint(0, 256, (3, 90, 120)).astype(np.uint8),
+            rng.randint(0, 256, (3, 100, 80)).astype(np.uint8)]
+    bboxes, masks, labels, scores = model.predict(imgs)
+    for img, b, m, l, s in zip(imgs, bboxes, masks, labels, scores):
+        assert b.shape == (0, 4) and b.dtype == np.float32
+        assert l.shape == (0,) and l.dtype == np.int32 and s.shape == (0,) and s.dtype == np.float32
+        assert m.shape == (0,) + img.shape[1:] and m.dtype == bool
