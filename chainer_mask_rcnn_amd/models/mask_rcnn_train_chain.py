@@ -111,20 +111,26 @@ class MaskRCNNTrainChain(torch.nn.Module):
         atc_jobs = None
         if hasattr(atc, 'prepare') and hasattr(atc, 'finish'):
             atc_jobs = [_pool().submit(atc.prepare, bbox, anchor_h, img_size) for bbox in bboxes]
+        pc = getattr(self.mask_rcnn.rpn, 'proposal_layer', None)
+        if pc is not None and hasattr(pc, 'keep_host_copy'):
+            pc.keep_host_copy = True       # proposals also as host arrays, same synchronisation
         rpn_locs, rpn_scores, rois, roi_indices, anchor = self.mask_rcnn.rpn(
             features, img_size, scales)
 
         # proposal targets: host-side sampling, exactly as the reference (:126-146)
         mark('extractor+rpn queued')
-        rois_h = rois.cpu().numpy()
-        roi_indices_h = roi_indices.cpu().numpy()
+        host_rois = getattr(pc, 'last_host_rois', None) if pc is not None else None
+        if host_rois is None:
+            rois_h = rois.cpu().numpy()
+            roi_indices_h = roi_indices.cpu().numpy()
+            host_rois = [rois_h[roi_indices_h == i] for i in range(batch_size)]
         mark('rois on host')
         ptc = self.proposal_target_creator
         split = hasattr(ptc, 'sample') and hasattr(ptc, 'mask_targets')
         sample_rois, sample_roi_indices = [], []
         gt_roi_locs, gt_roi_labels, gt_roi_masks, mask_jobs = [], [], [], []
         for batch_index, (bbox, label, mask) in enumerate(zip(bboxes, labels, masks)):
-            roi = rois_h[roi_indices_h == batch_index]
+            roi = host_rois[batch_index]
             if split:
                 sample_roi, gt_roi_loc, gt_roi_label, job = ptc.sample(roi, bbox, label)
                 mask_jobs.append((job, mask))

@@ -21,6 +21,8 @@ class ProposalCreator(object):
         self.force_cpu_nms = force_cpu_nms   # accepted for interface parity; no CPU path exists
         self.min_size = min_size
         self.train = True                    # chainer.config.train
+        self.keep_host_copy = False          # set by MaskRCNNTrainChain (see batch())
+        self.last_host_rois = None
 
     def __call__(self, loc, score, anchor, img_size, scale=1., return_indices=False):
         """loc (S,4), score (S,), anchor (S,4) device tensors -> roi (R,4) device tensor."""
@@ -65,6 +67,16 @@ class ProposalCreator(object):
             counts[i:i + 1] = n_sorted
         keep, n_keep = P.nms_sorted_batched(sorted_rois, counts, self.nms_thresh,
                                             limit=n_post if n_post > 0 else 0)
-        n_keep = n_keep.cpu().tolist()           # the one host synchronisation
+        if self.keep_host_copy:
+            # one synchronisation brings the counts AND the data the host needs to form its
+            # own copy of the proposals (the train chain samples RoIs on the host): the
+            # device gather below then runs without a second device-to-host round trip
+            n_keep_h, keep_h, sorted_h = n_keep.cpu(), keep.cpu(), sorted_rois.cpu()
+            n_keep = n_keep_h.tolist()
+            keep_np, sorted_np = keep_h.numpy(), sorted_h.numpy()
+            self.last_host_rois = [sorted_np[i][keep_np[i, :n_keep[i]]] for i in range(n)]
+        else:
+            n_keep = n_keep.cpu().tolist()       # the one host synchronisation
+            self.last_host_rois = None
         return [P.gather_rows(sorted_rois[i], keep[i, :n_keep[i]].contiguous())
                 for i in range(n)]

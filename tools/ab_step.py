@@ -30,6 +30,10 @@ def toggles(name):
         import chainer_mask_rcnn_amd.functions.conv as C
         return (lambda: setattr(C, 'PRETRANSPOSE_FILTERS', True)), \
                (lambda: setattr(C, 'PRETRANSPOSE_FILTERS', False))
+    if name == 'wside_all':
+        import chainer_mask_rcnn_amd.functions.conv as C
+        return (lambda: setattr(C, 'SMALL_WGRAD_MAX_PIXELS', 1 << 30)), \
+               (lambda: setattr(C, 'SMALL_WGRAD_MAX_PIXELS', 40000))
     raise SystemExit('unknown toggle ' + name)
 
 
@@ -46,9 +50,19 @@ def main():
     model, chain, opt, sync = bench.build_trainer(50, dev, 1, 2)
     imgs_d = torch.tensor(imgs, device=dev).contiguous(memory_format=torch.channels_last)
 
+    hi = torch.cuda.Stream(priority=-1) if os.environ.get('AB_HIGH_PRIO_MAIN') else None
+    print('stream priority range', torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else None)
+
     def run(n):
-        for _ in range(n):
-            opt.update(chain, imgs_d, bboxes, labels, masks, scales)
+        if hi is not None:
+            hi.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(hi):
+                for _ in range(n):
+                    opt.update(chain, imgs_d, bboxes, labels, masks, scales)
+            torch.cuda.current_stream().wait_stream(hi)
+        else:
+            for _ in range(n):
+                opt.update(chain, imgs_d, bboxes, labels, masks, scales)
         torch.cuda.synchronize()
 
     res = {'on': [], 'off': []}
