@@ -47,6 +47,7 @@ SIGNATURES = {
     'mrcnn_decode_clip': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_f32, c_f32, c_vp]),
     'mrcnn_topk_workspace_bytes': (c_i64, [c_int]),
     'mrcnn_topk_desc': (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'mrcnn_topk_desc_batched': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mrcnn_detect_sort_workspace_bytes': (c_i64, [c_int, c_int]),
     'mrcnn_detect_sort': (c_int, [c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'mrcnn_gather_rows': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),

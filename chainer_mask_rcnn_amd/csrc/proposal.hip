@@ -11,6 +11,8 @@
 // separately rounded fp32 operations NumPy performs.
 #include <algorithm>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -64,11 +66,23 @@ constexpr int kBuckets = 1 << 16;
 constexpr int kRankSplits = 8;   // a bucket's compare loop is split 8 ways (degenerate inputs:
                                  // all scores equal -> one bucket of n keys)
 
+// Several problems of the same size per launch: blockIdx.z = problem; workspace pointers
+// advance by ws_stride bytes, score / valid by n elements.
+template <typename T>
+__device__ __forceinline__ T *grp(T *p, int64_t stride_bytes)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<
+        typename std::remove_const<T>::type *>(p)) + (int64_t)blockIdx.z * stride_bytes);
+}
+
 __global__ void topk_keys_kernel(const float *__restrict__ score,
                                  const uint8_t *__restrict__ valid, int n,
                                  uint64_t *__restrict__ keys, int32_t *__restrict__ hist,
-                                 int32_t *__restrict__ n_valid)
+                                 int32_t *__restrict__ n_valid, int64_t ws_stride)
 {
+    score += (int64_t)blockIdx.z * n;
+    if (valid) valid += (int64_t)blockIdx.z * n;
+    keys = grp(keys, ws_stride); hist = grp(hist, ws_stride); n_valid = grp(n_valid, ws_stride);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool v = false;
     if (i < n) {
@@ -83,8 +97,9 @@ __global__ void topk_keys_kernel(const float *__restrict__ score,
 
 // start[b] = number of keys in buckets above b (one workgroup of 1024 threads)
 __global__ void __launch_bounds__(1024)
-topk_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ start)
+topk_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ start, int64_t ws_stride)
 {
+    hist = grp(hist, ws_stride); start = grp(start, ws_stride);
     __shared__ int part[1024];
     const int t = threadIdx.x;
     constexpr int PER = kBuckets / 1024;
@@ -110,8 +125,10 @@ topk_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ start)
 // counting sort by bucket (order inside a bucket is arbitrary); consumes hist
 __global__ void topk_place_kernel(const uint64_t *__restrict__ keys, int n,
                                   int32_t *__restrict__ hist, const int32_t *__restrict__ start,
-                                  uint64_t *__restrict__ sorted)
+                                  uint64_t *__restrict__ sorted, int64_t ws_stride)
 {
+    keys = grp(keys, ws_stride); hist = grp(hist, ws_stride); start = grp(start, ws_stride);
+    sorted = grp(sorted, ws_stride);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t key = keys[i];
@@ -122,8 +139,9 @@ __global__ void topk_place_kernel(const uint64_t *__restrict__ keys, int n,
 // grid (n / 256, kRankSplits): within-bucket count of larger keys, slice blockIdx.y
 __global__ void __launch_bounds__(256)
 topk_rank_kernel(const uint64_t *__restrict__ sorted, const int32_t *__restrict__ start, int n,
-                 int32_t *__restrict__ rank)
+                 int32_t *__restrict__ rank, int64_t ws_stride)
 {
+    sorted = grp(sorted, ws_stride); start = grp(start, ws_stride); rank = grp(rank, ws_stride);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const uint64_t key = sorted[p];
@@ -141,8 +159,12 @@ __global__ void topk_scatter_kernel(const uint64_t *__restrict__ sorted,
                                     const int32_t *__restrict__ rank, int n, int k,
                                     int32_t *__restrict__ order,
                                     const int32_t *__restrict__ n_valid,
-                                    int32_t *__restrict__ n_out)
+                                    int32_t *__restrict__ n_out, int64_t ws_stride, int order_stride)
 {
+    sorted = grp(sorted, ws_stride); start = grp(start, ws_stride); rank = grp(rank, ws_stride);
+    n_valid = grp(n_valid, ws_stride);
+    order += (int64_t)blockIdx.z * order_stride;
+    n_out += blockIdx.z;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p == 0) *n_out = min(k, *n_valid);
     if (p >= n) return;
@@ -220,18 +242,21 @@ extern "C" int64_t mrcnn_topk_workspace_bytes(int n)
     return (int64_t)n * 20 + 2 * (int64_t)kBuckets * 4 + 256;
 }
 
-extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, int k,
-                               int32_t *order, int32_t *n_out, void *ws, void *stream)
+extern "C" int mrcnn_topk_desc_batched(const float *score, const uint8_t *valid, int groups, int n,
+                                       int k, int32_t *order, int32_t *n_out, void *ws,
+                                       void *stream)
 {
-    MRCNN_REQUIRE(n >= 0 && k >= 0, "topk_desc: bad n/k");
+    MRCNN_REQUIRE(n >= 0 && k >= 0 && groups >= 0 && groups <= 65535, "topk_desc: bad n/k/groups");
+    if (groups == 0) return 0;
     MRCNN_REQUIRE(n == 0 || (score && order && n_out && ws), "topk_desc: null pointer");
     hipStream_t s = mrcnn::as_stream(stream);
     if (n == 0) {
-        if (n_out) MRCNN_HIP_TRY(hipMemsetAsync(n_out, 0, 4, s));
+        if (n_out) MRCNN_HIP_TRY(hipMemsetAsync(n_out, 0, 4 * (size_t)groups, s));
         return 0;
     }
-    // workspace: [n_valid | pad to 64 B][rank n x i32][pad][hist 64K x i32] (zeroed) then
-    // [start 64K x i32][keys n x u64][sorted n x u64]
+    // per-problem workspace: [n_valid | pad to 64 B][rank n x i32][pad][hist 64K x i32] (zeroed)
+    // then [start 64K x i32][keys n x u64][sorted n x u64]; problems ws_stride bytes apart
+    const int64_t ws_stride = ((mrcnn_topk_workspace_bytes(n) + 63) / 64) * 64;
     char *w = (char *)ws;
     int32_t *n_valid = (int32_t *)w;
     int32_t *rank = (int32_t *)(w + 64);
@@ -241,19 +266,26 @@ extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, 
     int32_t *start = (int32_t *)(w + start_off);
     uint64_t *keys = (uint64_t *)(w + start_off + (size_t)kBuckets * 4);
     uint64_t *sorted = keys + n;
-    MRCNN_HIP_TRY(hipMemsetAsync(ws, 0, start_off, s));
-    const int blocks = (int)mrcnn::ceil_div(n, 256);
-    mrcnn::ProfScope prof(mrcnn::PROF_TOPK, 0., 40.0 * n + 3.0 * 4 * kBuckets, s);
-    hipLaunchKernelGGL(topk_keys_kernel, dim3(blocks), dim3(256), 0, s, score, valid, n, keys, hist,
-                       n_valid);
-    hipLaunchKernelGGL(topk_scan_kernel, dim3(1), dim3(1024), 0, s, hist, start);
-    hipLaunchKernelGGL(topk_place_kernel, dim3(blocks), dim3(256), 0, s, keys, n, hist, start,
-                       sorted);
-    hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks, kRankSplits), dim3(256), 0, s, sorted, start,
-                       n, rank);
-    hipLaunchKernelGGL(topk_scatter_kernel, dim3(blocks), dim3(256), 0, s, sorted, start, rank, n,
-                       k, order, n_valid, n_out);
+    for (int g = 0; g < groups; ++g)
+        MRCNN_HIP_TRY(hipMemsetAsync(w + g * ws_stride, 0, start_off, s));
+    const unsigned blocks = (unsigned)mrcnn::ceil_div(n, 256), G = (unsigned)groups;
+    mrcnn::ProfScope prof(mrcnn::PROF_TOPK, 0., groups * (40.0 * n + 3.0 * 4 * kBuckets), s);
+    hipLaunchKernelGGL(topk_keys_kernel, dim3(blocks, 1, G), dim3(256), 0, s, score, valid, n, keys,
+                       hist, n_valid, ws_stride);
+    hipLaunchKernelGGL(topk_scan_kernel, dim3(1, 1, G), dim3(1024), 0, s, hist, start, ws_stride);
+    hipLaunchKernelGGL(topk_place_kernel, dim3(blocks, 1, G), dim3(256), 0, s, keys, n, hist, start,
+                       sorted, ws_stride);
+    hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks, kRankSplits, G), dim3(256), 0, s, sorted,
+                       start, n, rank, ws_stride);
+    hipLaunchKernelGGL(topk_scatter_kernel, dim3(blocks, 1, G), dim3(256), 0, s, sorted, start, rank,
+                       n, k, order, n_valid, n_out, ws_stride, k);
     return mrcnn::check_launch("topk_desc");
+}
+
+extern "C" int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, int k,
+                               int32_t *order, int32_t *n_out, void *ws, void *stream)
+{
+    return mrcnn_topk_desc_batched(score, valid, 1, n, k, order, n_out, ws, stream);
 }
 
 // ---- per-class score threshold + stable sort + gather for MaskRCNN._suppress ----------------

@@ -10,18 +10,40 @@ import torch
 from .. import _lib
 
 
-def decode_clip(anchor, loc, img_size, min_size=0.):
-    """loc2bbox + clip (+ min-size validity). anchor, loc: (n,4) -> roi (n,4), valid (n,) uint8."""
+def decode_clip(anchor, loc, img_size, min_size=0., out=None):
+    """loc2bbox + clip (+ min-size validity). anchor, loc: (n,4) -> roi (n,4), valid (n,) uint8
+    (``out`` = preallocated contiguous (roi, valid) to write into)."""
     _lib.require_device(anchor, loc)
     n = anchor.shape[0]
     anchor = anchor.contiguous()
     loc = loc.contiguous()
-    roi = torch.empty((n, 4), dtype=torch.float32, device=loc.device)
-    valid = torch.empty((n,), dtype=torch.uint8, device=loc.device)
+    if out is not None:
+        roi, valid = out
+    else:
+        roi = torch.empty((n, 4), dtype=torch.float32, device=loc.device)
+        valid = torch.empty((n,), dtype=torch.uint8, device=loc.device)
     _lib.call('mrcnn_decode_clip', _lib.ptr(anchor), _lib.ptr(loc), _lib.ptr(roi),
               _lib.ptr(valid), n, float(img_size[0]), float(img_size[1]),
               float(min_size), _lib.stream_ptr())
     return roi, valid
+
+
+def topk_desc_batched(score, k, valid=None):
+    """Stable descending top-k of every row of score (G, n) (valid (G, n) uint8 or None).
+    Returns (order int32 (G, k), n_out int32 (G,))."""
+    _lib.require_device(score)
+    score = score.contiguous()
+    G, n = score.shape
+    k = int(min(k, n)) if k > 0 else n
+    order = torch.empty((G, max(k, 1)), dtype=torch.int32, device=score.device)
+    n_out = torch.empty((G,), dtype=torch.int32, device=score.device)
+    per = (_lib.load().mrcnn_topk_workspace_bytes(n) + 63) // 64 * 64
+    ws = _lib.workspace(per * G, score.device, 'topk')
+    if valid is not None:
+        valid = valid.contiguous()
+    _lib.call('mrcnn_topk_desc_batched', _lib.ptr(score), _lib.ptr(valid), G, n, k,
+              _lib.ptr(order), _lib.ptr(n_out), _lib.ptr(ws), _lib.stream_ptr())
+    return order, n_out
 
 
 def topk_desc(score, k, valid=None):

@@ -58,13 +58,17 @@ class ProposalCreator(object):
         k = min(n_pre, S) if n_pre > 0 else S
         dev = anchor.device
         sorted_rois = torch.empty((n, k, 4), dtype=torch.float32, device=dev)
-        counts = torch.empty((n,), dtype=torch.int32, device=dev)
+        roi_all = torch.empty((n, S, 4), dtype=torch.float32, device=dev)
+        valid_all = torch.empty((n, S), dtype=torch.uint8, device=dev)
         for i in range(n):
-            roi, valid = P.decode_clip(anchor, locs[i].detach(), img_size,
-                                       float(self.min_size) * float(scales[i]))
-            order, n_sorted = P.topk_desc(scores[i].detach().reshape(-1), k, valid)
-            sorted_rois[i] = P.gather_rows(roi, order, n_sorted)
-            counts[i:i + 1] = n_sorted
+            P.decode_clip(anchor, locs[i].detach(), img_size,
+                          float(self.min_size) * float(scales[i]), out=(roi_all[i], valid_all[i]))
+        # every image's top-k in one set of launches
+        score_all = torch.stack([scores[i].detach().reshape(-1) for i in range(n)]) \
+            if not (torch.is_tensor(scores) and scores.dim() == 2) else scores.detach()
+        order, counts = P.topk_desc_batched(score_all, k, valid_all)
+        for i in range(n):
+            sorted_rois[i] = P.gather_rows(roi_all[i], order[i], counts[i:i + 1])
         keep, n_keep = P.nms_sorted_batched(sorted_rois, counts, self.nms_thresh,
                                             limit=n_post if n_post > 0 else 0)
         if self.keep_host_copy:

@@ -111,6 +111,11 @@ int mrcnn_decode_clip(const float *anchor, const float *loc, float *roi,
 int64_t mrcnn_topk_workspace_bytes(int n);
 int mrcnn_topk_desc(const float *score, const uint8_t *valid, int n, int k,
                     int32_t *order, int32_t *n_out, void *ws, void *stream);
+/* `groups` problems of the same size in one set of launches (a batch's images): score and
+ * valid are (groups, n), order (groups, k), n_out (groups); ws holds
+ * groups x round_up(mrcnn_topk_workspace_bytes(n), 64) bytes. */
+int mrcnn_topk_desc_batched(const float *score, const uint8_t *valid, int groups, int n, int k,
+                            int32_t *order, int32_t *n_out, void *ws, void *stream);
 /* dst[j,:] = src[idx[j],:] for j < *n_dev (n_dev device int32, rows of `cols`
  * fp32); rows j >= *n_dev up to n_max are zero-filled. */
 int mrcnn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev,

@@ -171,3 +171,19 @@ def test_full_proposal_pipeline_matches_oracle(dev):
     assert nk == len(ref_roi)
     assert np.array_equal(idx, ref_idx)
     assert np.array_equal(out.cpu().numpy(), ref_roi)
+
+
+def test_topk_batched_equals_per_row(dev):
+    rng = np.random.RandomState(5)
+    G, n, k = 3, 20000, 6000
+    score = rng.standard_normal((G, n)).astype(np.float32)
+    score[1, rng.randint(0, n, 2000)] = 0.5
+    valid = (rng.uniform(size=(G, n)) > 0.3).astype(np.uint8)
+    valid[2] = 1
+    order, n_out = P.topk_desc_batched(torch.tensor(score, device=dev), k, torch.tensor(valid, device=dev))
+    order, n_out = order.cpu().numpy(), n_out.cpu().numpy()
+    for g in range(G):
+        idx = np.where(valid[g] > 0)[0]
+        ref = idx[np_ref.stable_argsort_desc(score[g][idx])][:k]
+        assert n_out[g] == len(ref)
+        assert np.array_equal(order[g, :len(ref)], ref.astype(np.int32))
