@@ -203,3 +203,26 @@ def test_mask_branch_fg_only_is_results_identical(dev):
         assert abs(out[False][0][k] - out[True][0][k]) <= 1e-5 * max(abs(out[False][0][k]), 1e-3), k
     for n, g in out[False][1].items():
         assert _rel(out[True][1][n], g) < 1e-4, n
+
+
+def test_training_is_bit_reproducible_run_to_run(dev):
+    """Same seeds, same inputs -> bit-identical losses and weights after three SGD steps: no
+    kernel on the path depends on the order of floating-point atomics (ordered split-K slabs,
+    pixel-owner ROIAlign backward, two-stage loss reductions)."""
+    def run():
+        model, chain, imgs, bboxes, labels, masks = _build(dev)
+        opt = optimizers.MomentumSGD(lr=0.002, momentum=0.9)
+        opt.setup(chain)
+        opt.add_hook(optimizers.WeightDecay(1e-4))
+        x = torch.tensor(imgs, device=dev)
+        np.random.seed(5)
+        losses = []
+        for _ in range(3):
+            loss = opt.update(chain, x, bboxes, labels, masks, [1., 1.])
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        return losses, opt.arena.values.clone()
+    l1, w1 = run()
+    l2, w2 = run()
+    assert all(np.isfinite(l1)) and l1 == l2
+    assert torch.equal(w1, w2)
