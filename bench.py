@@ -262,6 +262,9 @@ def main():
     ap.add_argument('--width', type=int, default=1333)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--lr-batch', type=int, default=0,
+                    help='override the global batch the learning-rate rule uses (developer: '
+                         'try the 8-GPU learning rate on one GPU)')
     ap.add_argument('--profile-all', action='store_true',
                     help='time every kernel kind (default: only the 128x128 GEMM kinds, the '
                          'roofline candidates, so that the timed region is barely perturbed)')
@@ -301,7 +304,8 @@ def main():
 
     rng = np.random.RandomState(rank)
     imgs, bboxes, labels, masks, scales = synthetic_batch(rng, args.batch, args.height, args.width)
-    model, chain, opt, sync = build_trainer(args.layers, device, world, args.batch * world,
+    model, chain, opt, sync = build_trainer(args.layers, device, world,
+                                            args.lr_batch or args.batch * world,
                                             force_dp=args.force_dp)
     imgs_d = torch.tensor(imgs, device=device).contiguous(memory_format=torch.channels_last)
 
@@ -372,7 +376,8 @@ def main():
                         '(fwd+bwd+SGD), batch %dx%dx%d fp32 per GPU, %d sampled RoIs/step/GPU'
                         % (args.layers, args.batch, args.height, args.width, n_rois),
                         global_batch=global_batch, rois_per_image=n_rois // args.batch,
-                        parallelism='dp%d' % world, loss=round(loss_val, 5),
+                        parallelism='dp%d' % world,
+                        loss=round(loss_val, 5) if np.isfinite(loss_val) else None,
                         # reference algorithm (mask branch on all 512 RoIs/img)
                         reference_gflop_per_image=TRAIN_GFLOP_PER_IMAGE[args.layers],
                         # what the GEMM kernels executed (the mask branch runs on foreground
