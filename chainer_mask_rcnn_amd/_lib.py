@@ -56,6 +56,7 @@ SIGNATURES = {
     'mrcnn_nms_sorted_batched': (c_int, [c_vp, c_vp, c_int, c_int, c_f32, c_int, c_vp, c_vp,
                                          c_vp, c_vp]),
     'mrcnn_conv2d_split_workspace_bytes': (c_i64, []),
+    'mrcnn_set_tuning': (c_int, [ctypes.c_char_p, c_int]),
     'mrcnn_conv2d_fwd': (c_int, [_DP] + [c_vp] * 7 + [c_int, c_vp, c_vp]),
     'mrcnn_conv2d_dgrad': (c_int, [_DP, c_vp, c_vp, c_vp, c_int, c_vp]),
     'mrcnn_conv2d_wgrad_workspace_bytes': (c_i64, [_DP]),

@@ -24,6 +24,7 @@
 // K block MFMA step t pairs k = 4*half + t of both operands (any pairing is
 // valid as long as A and B agree).
 #include <algorithm>
+#include <cstring>
 
 #include "common.h"
 
@@ -116,6 +117,14 @@ struct GemmParams {
     int split_len;       // WGRAD: pixels per split; FWD/DGRAD: K slices per split (0: no split)
     int64_t split_stride;// floats between split slabs
     int out_row0;        // FWD/DGRAD split launches: first row of the slab (subtracted)
+    // Forward-form launches on many small maps (RoI features): GEMM rows ordered
+    // (block of kPermBlock images, position, image in block): a 128-row tile holds ONE pixel
+    // position of 128 images, so a filter tap that falls into the zero padding for that
+    // position does so for EVERY row of the tile and its K slices are skipped (a 3x3 / pad 1
+    // convolution on 7x7 maps: 18 % of all slices); consecutive tiles walk the positions of
+    // the same image block, whose pixels therefore stay in the XCD's L2.  perm_n = number of
+    // images (M is padded to whole blocks), 0 = natural (image, y, x) order.
+    int perm_n;
     // WGRAD in-kernel slab reduction: per-tile arrival counters (zeroed by the host) and the
     // final gradient; the last workgroup of a tile to arrive sums the slabs in slab order
     int *tile_counters;
@@ -138,6 +147,19 @@ struct GemmParams {
 #ifdef MRCNN_GEMM_TRACE
 __device__ unsigned long long g_trace[64 * 4 * 64 * 5];
 #endif
+
+// GEMM row -> (image, position) under the block-position-major order of GemmParams::perm_n
+constexpr int kPermBlock = 128;
+struct PermRow { int n, pos; };
+__host__ __device__ __forceinline__ PermRow perm_row(int m, int pq)
+{
+    const int q = m / kPermBlock, img = m - q * kPermBlock;
+    const int blk = q / pq;
+    PermRow r;
+    r.pos = q - blk * pq;
+    r.n = blk * kPermBlock + img;
+    return r;
+}
 
 template <int TM, int TN, int MODE>
 struct Cfg {
@@ -199,10 +221,13 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
 // Measured on MI355X (round 1): the strict antiphase is SLOWER (res5 3x3 fwd 110 vs 122 TF/s):
 // one wave per SIMD cannot keep the fp32 MFMA pipe as full as two interleaved waves do.  Kept
 // as a compile-time experiment (-DMRCNN_GEMM_PINGPONG=1), off by default.
-template <int TM, int TN, int MODE, bool MASKED, bool PP>
+// WPERM: WGRAD with position-major pixel order (GemmParams::perm_n) — a separate instantiation
+// because the natural-order kernel sits exactly at its 168-register budget.
+template <int TM, int TN, int MODE, bool MASKED, bool PP, bool WPERM = false>
 __global__ void __launch_bounds__(PP ? 512 : 256, min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
+    static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
     constexpr bool SINGLEBUF = single_buffered(TM, MODE, MASKED) && !PP;
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
@@ -250,13 +275,20 @@ conv_gemm_kernel(const GemmParams p)
             const int m = m0 + kc_row + KC_RPP * i;
             const bool ok = m < p.M;
             const int mm = ok ? m : 0;
-            const int n = mm / (p.gp * p.gq);
-            const int rem = mm - n * (p.gp * p.gq);
+            int n, rem;
+            bool img_ok = true;
+            if (FWDLIKE && p.perm_n > 0) {
+                const PermRow pr = perm_row(mm, p.gp * p.gq);
+                n = pr.n; rem = pr.pos;
+                img_ok = n < p.perm_n;           // padding rows of the last image block
+            } else {
+                n = mm / (p.gp * p.gq); rem = mm - n * (p.gp * p.gq);
+            }
             const int gy = rem / p.gq, gx = rem - gy * p.gq;
             a_n[i] = n;
             if (FWDLIKE) { a_y[i] = gy * p.stride - p.pad; a_x[i] = gx * p.stride - p.pad; }
             else { a_y[i] = gy + p.pad; a_x[i] = gx + p.pad; }
-            if (!ok) a_y[i] = -(1 << 28);          // row beyond M: every tap out of range
+            if (!ok || !img_ok) a_y[i] = -(1 << 28);   // no such row: every tap out of range
         }
     }
     constexpr int A_TPR = BM / 4, B_TPR = BN / 4;            // threads per k row (K-strided tiles)
@@ -264,6 +296,8 @@ conv_gemm_kernel(const GemmParams p)
     const int wa_k = tid / A_TPR, wa_c4 = tid % A_TPR;
     const int wb_k = tid / B_TPR, wb_c4 = tid % B_TPR;
     int wr = 0, ws_ = 0, wc = 0;
+    int wy_lo = 0, wx_lo = 0, wnvx = 1;   // WGRAD position-major: valid-position rectangle
+    int wr_u = 0, ws_u = 0, wnv = 1;      // ... the tile's tap and its position count, uniform
     bool wcol_ok = false;
     int pn[BV], py[BV], px[BV];
     int k_begin = 0, k_end = 0;
@@ -276,15 +310,32 @@ conv_gemm_kernel(const GemmParams p)
         wr = rs / p.S;
         ws_ = rs - wr * p.S;
         k_begin = split * p.split_len;
-        k_end = min(p.Kc, k_begin + p.split_len);
+        if (WPERM) {
+            // Pixel order for the reduction: (block of BK images, position, image in block),
+            // restricted to the positions whose tap (wr, ws_) lies inside the map — one K
+            // slice = one position of BK consecutive images, and a block's positions follow
+            // each other so its pixels stay in L2.  Every column of the tile belongs to the
+            // same tap (cin % BN == 0, checked by the host): tile-uniform values live in SGPRs.
+            wr_u = __builtin_amdgcn_readfirstlane(wr);
+            ws_u = __builtin_amdgcn_readfirstlane(ws_);
+            wy_lo = max(0, p.pad - wr_u);
+            wx_lo = max(0, p.pad - ws_u);
+            const int nvy = min(p.gp - 1, p.sh - 1 + p.pad - wr_u) - wy_lo + 1;
+            wnvx = max(min(p.gq - 1, p.sw - 1 + p.pad - ws_u) - wx_lo + 1, 0);
+            wnv = max(nvy, 0) * wnvx;
+            const int nblk = (p.perm_n + BK - 1) / BK;
+            k_end = min(nblk * wnv * BK, k_begin + p.split_len);
+        } else {
+            k_end = min(p.Kc, k_begin + p.split_len);
 #pragma unroll
-        for (int i = 0; i < BV; ++i) {
-            const int m = k_begin + wb_k + B_RPP * i;
-            const int n = m / (p.gp * p.gq);
-            const int rem = m - n * (p.gp * p.gq);
-            pn[i] = n;
-            py[i] = rem / p.gq;
-            px[i] = rem - py[i] * p.gq;
+            for (int i = 0; i < BV; ++i) {
+                const int m = k_begin + wb_k + B_RPP * i;
+                const int n = m / (p.gp * p.gq);
+                const int rem = m - n * (p.gp * p.gq);
+                pn[i] = n;
+                py[i] = rem / p.gq;
+                px[i] = rem - py[i] * p.gq;
+            }
         }
     }
 
@@ -292,8 +343,32 @@ conv_gemm_kernel(const GemmParams p)
     const int cprs = (MODE == WGRAD) ? 1 : (p.Kc + BK - 1) / BK;  // K slices per (r,s)
     // FWD/DGRAD split-K (leftover rows of a small-M problem, see launch()): this workgroup
     // runs slices [kt0, kt0 + nslices) and writes raw partial sums into its slab
+    // position-major rows: the taps that are inside the map for at least one position of this
+    // tile, as 4-bit indices packed into a word (wave-uniform)
+    int ntaps = p.R * p.S;
+    unsigned long long tap_list = 0;
+    if (FWDLIKE && p.perm_n > 0) {
+        const int q_lo = m0 / kPermBlock;
+        const int q_hi = min(p.M - 1, m0 + BM - 1) / kPermBlock;
+        const int pq = p.gp * p.gq;
+        ntaps = 0;
+        for (int rs = 0; rs < p.R * p.S; ++rs) {
+            const int r = rs / p.S, s = rs - r * p.S;
+            bool hit = q_hi - q_lo > 3;              // many positions in the tile: keep all
+            for (int qq = q_lo; qq <= q_hi && !hit; ++qq) {
+                const int q = qq % pq;
+                const int y = q / p.gq, x = q - y * p.gq;
+                hit = (unsigned)(y * p.stride - p.pad + r) < (unsigned)p.sh &&
+                      (unsigned)(x * p.stride - p.pad + s) < (unsigned)p.sw;
+            }
+            if (hit) {
+                tap_list |= (unsigned long long)rs << (4 * ntaps);
+                ++ntaps;
+            }
+        }
+    }
     int kt0 = 0;
-    int nslices = (MODE == WGRAD) ? (k_end - k_begin + BK - 1) / BK : p.R * p.S * cprs;
+    int nslices = (MODE == WGRAD) ? (k_end - k_begin + BK - 1) / BK : ntaps * cprs;
     if (MODE != WGRAD && p.split_len > 0) {
         kt0 = split * p.split_len;
         nslices = max(0, min(nslices - kt0, p.split_len));
@@ -342,8 +417,14 @@ conv_gemm_kernel(const GemmParams p)
     auto load_slice = [&](int kt) {
         if (FWDLIKE || MODE == DGRAD) {
             kt += kt0;
-            const int chunk = kt / RS;
-            const int rs = kt - chunk * RS;
+            int chunk, rs;
+            if (FWDLIKE && p.perm_n > 0) {
+                chunk = kt / ntaps;
+                rs = (int)((tap_list >> (4 * (kt - chunk * ntaps))) & 15ull);
+            } else {
+                chunk = kt / RS;
+                rs = kt - chunk * RS;
+            }
             const int c0 = chunk * BK;
             const int r = rs / p.S, s = rs - r * p.S;
             const int cc = c0 + kc_c4 * 4;
@@ -378,6 +459,28 @@ conv_gemm_kernel(const GemmParams p)
             }
         } else {
             const int kb = k_begin + kt * BK;
+            if (WPERM) {
+                // A and B rows of a thread are the same k rows (BM == BN); the slice's image
+                // block and position are wave-uniform
+                const int sidx = kb / BK;
+                const int blk = sidx / max(wnv, 1), pos = sidx - blk * max(wnv, 1);
+                const int yv = pos / max(wnvx, 1);
+                const int y = wy_lo + yv, x = wx_lo + pos - yv * wnvx;
+                const int a_col = m0 + wa_c4 * 4;
+                const int pix_a = y * p.gq + x;
+                const int pix_b = (y + wr_u - p.pad) * p.sw + x + ws_u - p.pad;
+#pragma unroll
+                for (int i = 0; i < BV; ++i) {
+                    const int r = wb_k + B_RPP * i;
+                    const int n = blk * BK + r;
+                    const bool ok = kb + r < k_end && n < p.perm_n;
+                    const unsigned offa = (unsigned)((n * (p.gp * p.gq) + pix_a) * p.ldg + a_col);
+                    ra[i] = bload4(rA, ok && a_col < p.M ? 4u * offa : kOOB);
+                    const unsigned offb = (unsigned)((n * (p.sh * p.sw) + pix_b) * p.lda + wc);
+                    rb[i] = bload4(rB, ok && wcol_ok ? 4u * offb : kOOB);
+                }
+                return;
+            }
             const unsigned gofs = (unsigned)(kb * p.ldg);
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
@@ -628,10 +731,15 @@ conv_gemm_kernel(const GemmParams p)
                             o = ((n * p.oh + gy * p.stride) * p.ow + gx * p.stride) * p.ldc + col_off;
                         else
                             o = ((n * (2 * p.gp) + 2 * gy) * (2 * p.gq) + 2 * gx) * p.ko + col_off;
+                    } else if (FWDLIKE && p.perm_n > 0 && p.split_len == 0) {
+                        // position-major GEMM row -> (image, position) row of the NHWC tensor
+                        // (split-K slabs stay indexed by GEMM row; the slab-sum kernel maps)
+                        const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
+                        o = pr.n < p.perm_n ? (pr.n * (p.gp * p.gq) + pr.pos) * p.ldc + col_off : -1;
                     } else {
                         o = (row - p.out_row0) * p.ldc + col_off;
                     }
-                    off[q] = (col_ok && row < p.M) ? 4u * (unsigned)o : kOOB;
+                    off[q] = (col_ok && row < p.M && o >= 0) ? 4u * (unsigned)o : kOOB;
                 }
                 float aux0[8], aux1[8], aux2[8], aux3[8];
                 if (MODE != WGRAD) {
@@ -783,6 +891,13 @@ void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t
         hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
                            dim3((unsigned)mrcnn::ceil_div(tiles, 2), splits), dim3(512), 0, s, p);
     } else {
+        if constexpr (MODE == WGRAD && !MASKED) {
+            if (p.perm_n > 0) {
+                hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
+                                   dim3((unsigned)tiles, splits), dim3(256), 0, s, p);
+                return;
+            }
+        }
         hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false>),
                            dim3((unsigned)tiles, splits), dim3(256), 0, s, p);
     }
@@ -830,6 +945,7 @@ struct FixParams {
     float *C;
     const float *bias, *scale, *shift, *residual, *res_g, *res_y, *out_mask_y;
     int splits, rows, N, row0, ldc, flags;
+    int perm_n, pq;      // position-major GEMM rows (see GemmParams::perm_n), positions per image
     int64_t stride;
 };
 
@@ -845,7 +961,13 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const FixParams f)
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     float v[4] = {a.x, a.y, a.z, a.w};
-    const int64_t off = (int64_t)(f.row0 + r) * f.ldc + c;
+    int orow = f.row0 + r;
+    if (f.perm_n > 0) {
+        const PermRow pr = perm_row(orow, f.pq);
+        if (pr.n >= f.perm_n) return;            // padding row of the last image block
+        orow = pr.n * f.pq + pr.pos;
+    }
+    const int64_t off = (int64_t)orow * f.ldc + c;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float x = v[k];
@@ -889,6 +1011,7 @@ void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_s
     f.res_g = p.res_g; f.res_y = p.res_y; f.out_mask_y = p.out_mask_y;
     f.splits = splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_lo; f.ldc = p.ldc;
     f.flags = p.flags; f.stride = q.split_stride;
+    f.perm_n = MODE == FWD ? p.perm_n : 0; f.pq = p.gp * p.gq;
     const int64_t n = (int64_t)rows_left * (p.N / 4);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0,
                        s, f);
@@ -987,6 +1110,18 @@ int check_desc(const mrcnn_conv_desc *d)
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p % 16) == 0; }
 
+int g_position_major_rows = 1;    // mrcnn_set_tuning("position_major_rows", 0/1)
+
+// Position-major row order (GemmParams::perm_n) pays when many small maps are convolved with
+// a padded filter: n_img maps of gp x gq output positions, pad_eff = padding of the gathered
+// tensor as the forward-form kernel sees it.
+inline int choose_perm(int n_img, int gp, int gq, int R, int S, int stride, int pad_eff)
+{
+    if (!g_position_major_rows || R * S <= 1 || R * S > 16 || stride != 1 || pad_eff <= 0) return 0;
+    if (gp * gq > 256 || n_img < 64) return 0;
+    return n_img;
+}
+
 // buffer extents in floats -> bytes; 32-bit buffer offsets need every tensor < 2 GiB
 int set_extents(GemmParams &p, int64_t a_floats, int64_t b_floats, int64_t c_floats)
 {
@@ -1028,6 +1163,17 @@ extern "C" int mrcnn_gemm_trace_read(unsigned long long *host, int n)
 
 extern "C" int64_t mrcnn_conv2d_split_workspace_bytes(void) { return kSplitWsBytes; }
 
+extern "C" int mrcnn_set_tuning(const char *name, int value)
+{
+    MRCNN_REQUIRE(name != nullptr, "set_tuning: null name");
+    if (strcmp(name, "position_major_rows") == 0) {
+        g_position_major_rows = value != 0;
+        return 0;
+    }
+    MRCNN_REQUIRE(false, "set_tuning: unknown option '%s'", name);
+    return 1;
+}
+
 extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                                 const float *bias, const float *scale, const float *shift,
                                 const float *residual, float *y, int epi_flags, void *split_ws,
@@ -1048,6 +1194,8 @@ extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const 
     p.lda = d->C; p.ldb = d->R * d->S * d->C; p.ldc = d->K;
     p.flags = epi_flags; p.out_mode = OUT_PLAIN;
     p.split_ws = (float *)split_ws;
+    p.perm_n = choose_perm(d->N, d->P, d->Q, d->R, d->S, d->stride, d->pad);
+    if (p.perm_n) p.M = (int)(mrcnn::ceil_div(d->N, kPermBlock) * kPermBlock) * d->P * d->Q;
     if (int rc = set_extents(p, (int64_t)d->N * d->H * d->W * d->C, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->P * d->Q * d->K))
         return rc;
@@ -1262,6 +1410,8 @@ extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, 
     p.R = d->R; p.S = d->S; p.stride = 1; p.pad = d->R - 1 - d->pad;
     p.lda = d->K; p.ldb = d->R * d->S * d->K; p.ldc = d->C;
     p.flags = epi_flags | (out_scale ? MRCNN_EPI_AFFINE : 0); p.out_mode = OUT_PLAIN;
+    p.perm_n = choose_perm(d->N, d->H, d->W, d->R, d->S, 1, p.pad);
+    if (p.perm_n) p.M = (int)(mrcnn::ceil_div(d->N, kPermBlock) * kPermBlock) * d->H * d->W;
     MRCNN_REQUIRE(d->S - 1 - d->pad == p.pad, "conv2d_dgrad_wt: square filters / symmetric padding only");
     if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->H * d->W * d->C))
@@ -1298,10 +1448,15 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     const int64_t slots_big = single_buffered(2, WGRAD, is_masked(p)) ? 768 : kSlotsBig;
     const bool use_big = p.N > 64 && p.M > 64 && big * max_splits * 2 >= kSlotsBig;
     const int64_t tiles = use_big ? big : small;
+    // block-position-major pixel order (WPERM kernel): border taps skip the positions where
+    // they fall into the padding; the reduction then runs over whole blocks of BK images
+    if (C % (use_big ? 128 : 64) == 0 && N_ >= BK && !is_masked(p))
+        p.perm_n = choose_perm(N_, P, Q, R, S, stride, pad);
+    const int64_t k_extent = p.perm_n ? mrcnn::ceil_div(N_, BK) * BK * P * Q : pixels;
     int splits = wgrad_splits(tiles, pixels, use_big ? slots_big : kSlotsSmall);
     if (!ws) splits = 1;
-    p.split_len = (int)(mrcnn::ceil_div(mrcnn::ceil_div(pixels, splits), BK) * BK);
-    splits = (int)mrcnn::ceil_div(pixels, p.split_len);
+    p.split_len = (int)(mrcnn::ceil_div(mrcnn::ceil_div(k_extent, splits), BK) * BK);
+    splits = (int)mrcnn::ceil_div(k_extent, p.split_len);
     p.split_stride = gwsz;
     if (int rc = set_extents(p, pixels * ldg, (int64_t)N_ * H * W * C, gwsz)) return rc;
     p.C = splits > 1 ? (float *)ws : gw;

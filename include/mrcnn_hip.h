@@ -162,6 +162,11 @@ typedef struct {
  * average 2.09) runs its leftover rows split along K into many short workgroups whose partial
  * sums are combined, in a fixed order, by a small epilogue kernel. */
 int64_t mrcnn_conv2d_split_workspace_bytes(void);
+/* Developer switches for A/B measurements (results are identical either way):
+ *   "position_major_rows" (default 1): forward-form convolutions over many small maps (RoI
+ *   features, 3x3 / pad 1 on 7x7) order their GEMM rows position-major so that the K slices of
+ *   filter taps that fall into the zero padding for every row of a tile are skipped. */
+int mrcnn_set_tuning(const char *name, int value);
 int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                      const float *bias, const float *scale, const float *shift,
                      const float *residual, float *y, int epi_flags, void *split_ws,

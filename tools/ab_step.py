@@ -34,6 +34,11 @@ def toggles(name):
         import chainer_mask_rcnn_amd.functions.conv as C
         return (lambda: setattr(C, 'SMALL_WGRAD_MAX_PIXELS', 1 << 30)), \
                (lambda: setattr(C, 'SMALL_WGRAD_MAX_PIXELS', 40000))
+    if name == 'posmajor':
+        from chainer_mask_rcnn_amd import _lib
+        lib = _lib.load()
+        return (lambda: lib.mrcnn_set_tuning(b'position_major_rows', 1)), \
+               (lambda: lib.mrcnn_set_tuning(b'position_major_rows', 0))
     raise SystemExit('unknown toggle ' + name)
 
 
