@@ -254,8 +254,8 @@ def bench_infer(args, device, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--layers', type=int, default=50, choices=[50, 101])
     ap.add_argument('--batch', type=int, default=2, help='images per GPU')
     ap.add_argument('--height', type=int, default=800)
@@ -266,8 +266,8 @@ def main():
                     help='override the global batch the learning-rate rule uses (developer: '
                          'try the 8-GPU learning rate on one GPU)')
     ap.add_argument('--profile-all', action='store_true',
-                    help='time every kernel kind (default: only the 128x128 GEMM kinds, the '
-                         'roofline candidates, so that the timed region is barely perturbed)')
+                    help='time every kernel kind (default: only the dominant forward-form 128x128 '
+                         'GEMM, so that the timed region is barely perturbed)')
     ap.add_argument('--workload', default='train', choices=['train', 'infer'],
                     help="'train' = BASELINE configs[1..3] (the headline metric); 'infer' = "
                          "configs[4]: inference-only 8x1024x1024, 1000 proposals/img")
@@ -323,8 +323,9 @@ def main():
     fence()
     lib = _lib.load()
     if not args.no_profile:
-        # mode 2: HIP events only around the 128x128 GEMM launches (the roofline candidates);
-        # every other kind just counts launches / flops / bytes
+        # mode 2: HIP events only around the forward-form 128x128 GEMM launches (the dominant
+        # kernel symbol: half of the GPU time); every other kind just counts launches / flops /
+        # bytes.  --profile-all times everything.
         lib.mrcnn_profile_enable(1 if args.profile_all else 2)
     t0 = time.perf_counter()
     for _ in range(args.steps):

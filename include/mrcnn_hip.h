@@ -42,8 +42,9 @@ int mrcnn_device_info(int *n_cu, char *name, int name_len);
  * enabled.  bench.py uses it to report roofline numbers (average launch duration and
  * algorithmic flops / bytes per kernel kind; kinds follow the kernel symbols rocprofv3
  * reports).  mrcnn_profile_enable(mode) clears the records; mode 0 = off, 1 = every kind,
- * 2 = only the 128x128 conv-GEMM kinds (the roofline candidates: ~90 instead of ~500 event
- * pairs per train step, so the timed region is barely perturbed);
+ * 2 = only the forward-form 128x128 conv GEMM, the dominant kernel symbol (~48 instead of
+ * ~500 event pairs per train step, so the timed region is barely perturbed; the other kinds
+ * still count launches / flops / bytes);
  * mrcnn_profile_summary sums the records (synchronise the stream first). */
 int mrcnn_profile_enable(int on);
 int mrcnn_profile_num_kinds(void);
