@@ -84,6 +84,9 @@ constexpr int min_blocks(int tm, int mode, bool masked)
 #define MRCNN_WGRAD_INKERNEL_REDUCE 0
 #endif
 constexpr int64_t kWgradCounterBytes = 1 << 20;   // >= 4 B x tiles for any supported filter
+#ifndef MRCNN_GEMM_WIDE_EPILOGUE
+#define MRCNN_GEMM_WIDE_EPILOGUE 1
+#endif
 constexpr int KPAD = 4;  // K-contiguous LDS rows are 36 floats (conflict-free b128)
 
 // The stride-1 dgrad is also run in FWD mode: a forward convolution of gy with the flipped,
@@ -201,6 +204,13 @@ __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off)
 __device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, unsigned off, float v)
 {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
+}
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v)
+{
+    u32x4 u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y);
+    u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 0);
 }
 __device__ __forceinline__ float4 relu_mask(float4 v, float4 y)
 {
@@ -697,6 +707,109 @@ conv_gemm_kernel(const GemmParams p)
     const bool f_resg = MODE != WGRAD && p.res_g != nullptr;
     const bool f_resy = f_resg && p.res_y != nullptr;
     const bool f_outm = MODE != WGRAD && p.out_mask_y != nullptr;
+    constexpr int EG = 8;       // accumulator rows handled per batch of auxiliary loads
+
+    if constexpr (MODE == FWD && TM == 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
+        // Forward-form launches: the accumulators (one column x 16 rows per lane) are turned
+        // into row-major float4s through the wave's corner of the LDS stages, so the residual
+        // / mask reads and the output stores are 16 B per lane — a quarter of the memory
+        // instructions of the per-element path below.  K-short layers (a bottleneck's conv3:
+        // 16 K slices, 411 MB written + 411 MB residual read) spend a quarter of their time here.
+        constexpr int CW = 32 * TN;                 // columns of the wave's quadrant
+        constexpr int LDW = CW + 4;                 // padded LDS row
+        constexpr int F4 = CW / 4, RPI = 64 / F4;   // float4 per row, rows per pass of the wave
+        constexpr int NK = 32 / RPI;                // passes per 32-row half
+        constexpr int QG = TM == 2 ? 4 : 2;         // passes whose loads are in flight together
+        __syncthreads();                            // every wave is done with the K loop's LDS
+        float *ep = &smem_all[0][0][0] + wave * (32 * LDW);
+        const int c4 = lane % F4, r_in = lane / F4;
+        const int col = n0 + wn * CW + c4 * 4;
+        const bool col_ok = col < p.N;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scale4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 shift4 = bias4;
+        if (col_ok) {
+            if (f_bias) bias4 = *reinterpret_cast<const float4 *>(p.bias + col);
+            if (f_aff) {
+                scale4 = *reinterpret_cast<const float4 *>(p.scale + col);
+                if (p.shift) shift4 = *reinterpret_cast<const float4 *>(p.shift + col);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    ep[((e & 3) + 8 * (e >> 2) + 4 * lk) * LDW + j * 32 + li] = acc[i][j][e];
+            // same wave writes and reads: LDS operations of a wave execute in order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kg = 0; kg < NK; kg += QG) {
+                unsigned off[QG];
+                float4 v[QG], a0[QG], a1[QG], a2[QG], a3[QG];
+#pragma unroll
+                for (int q = 0; q < QG; ++q) {
+                    const int r = (kg + q) * RPI + r_in;
+                    v[q] = *reinterpret_cast<const float4 *>(ep + r * LDW + c4 * 4);
+                    const int row = m0 + wm * (32 * TM) + i * 32 + r;
+                    int o;
+                    if (p.perm_n > 0 && p.split_len == 0) {
+                        const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
+                        o = pr.n < p.perm_n ? (pr.n * (p.gp * p.gq) + pr.pos) * p.ldc + col : -1;
+                    } else {
+                        o = (row - p.out_row0) * p.ldc + col;
+                    }
+                    off[q] = (col_ok && row < p.M && o >= 0) ? 4u * (unsigned)o : kOOB;
+                }
+                if (f_res) {
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) a0[q] = bload4(rRes, off[q]);
+                }
+                if (f_acc) {
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) a1[q] = bload4(rC, off[q]);
+                }
+                if (f_resg) {
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) a0[q] = bload4(rResG, off[q]);
+                }
+                if (f_resy) {
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) a2[q] = bload4(rResY, off[q]);
+                }
+                if (f_outm) {
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) a3[q] = bload4(rOutM, off[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < QG; ++q) {
+                    float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                    const float b[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+                    const float sc[4] = {scale4.x, scale4.y, scale4.z, scale4.w};
+                    const float sh[4] = {shift4.x, shift4.y, shift4.z, shift4.w};
+                    const float r0[4] = {a0[q].x, a0[q].y, a0[q].z, a0[q].w};
+                    const float r1[4] = {a1[q].x, a1[q].y, a1[q].z, a1[q].w};
+                    const float r2[4] = {a2[q].x, a2[q].y, a2[q].z, a2[q].w};
+                    const float r3[4] = {a3[q].x, a3[q].y, a3[q].z, a3[q].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float y = x[t];
+                        if (f_bias) y += b[t];
+                        if (f_aff) y = y * sc[t] + sh[t];
+                        if (f_res) y += r0[t];
+                        if (f_acc) y += r1[t];
+                        if (f_resy) y += r2[t] > 0.f ? r0[t] : 0.f;
+                        else if (f_resg) y += r0[t];
+                        if (f_relu) y = fmaxf(y, 0.f);
+                        if (f_outm) y = r3[t] > 0.f ? y : 0.f;
+                        x[t] = y;
+                    }
+                    bstore4(rC, off[q], make_float4(x[0], x[1], x[2], x[3]));
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (32 * TN) + j * 32 + li;
@@ -715,11 +828,11 @@ conv_gemm_kernel(const GemmParams p)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {        // two groups of 8 accumulator rows
-                unsigned off[8];
+            for (int g = 0; g < 16 / EG; ++g) {  // groups of EG accumulator rows
+                unsigned off[EG];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int e = g * 8 + q;
+                for (int q = 0; q < EG; ++q) {
+                    const int e = g * EG + q;
                     const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                     int o;
                     if (MODE == DGRAD && p.out_mode != OUT_PLAIN) {
@@ -741,41 +854,41 @@ conv_gemm_kernel(const GemmParams p)
                     }
                     off[q] = (col_ok && row < p.M && o >= 0) ? 4u * (unsigned)o : kOOB;
                 }
-                float aux0[8], aux1[8], aux2[8], aux3[8];
+                float aux0[EG], aux1[EG], aux2[EG], aux3[EG];
                 if (MODE != WGRAD) {
                     if (f_res) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) aux0[q] = bload1(rRes, off[q]);
+                        for (int q = 0; q < EG; ++q) aux0[q] = bload1(rRes, off[q]);
                     }
                     if (f_acc) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) aux1[q] = bload1(rC, off[q]);
+                        for (int q = 0; q < EG; ++q) aux1[q] = bload1(rC, off[q]);
                     }
                     if (f_resg) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) aux0[q] = bload1(rResG, off[q]);
+                        for (int q = 0; q < EG; ++q) aux0[q] = bload1(rResG, off[q]);
                     }
                     if (f_resy) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) aux2[q] = bload1(rResY, off[q]);
+                        for (int q = 0; q < EG; ++q) aux2[q] = bload1(rResY, off[q]);
                     }
                     if (f_outm) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) aux3[q] = bload1(rOutM, off[q]);
+                        for (int q = 0; q < EG; ++q) aux3[q] = bload1(rOutM, off[q]);
                     }
                 }
-                float row_scale[8];
+                float row_scale[EG];
                 if (MODE == WGRAD && p.scale) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int e = g * 8 + q;
+                    for (int q = 0; q < EG; ++q) {
+                        const int e = g * EG + q;
                         const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                         row_scale[q] = row < p.M ? p.scale[row] : 0.f;
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float v = acc[i][j][g * 8 + q];
+                for (int q = 0; q < EG; ++q) {
+                    float v = acc[i][j][g * EG + q];
                     if (MODE != WGRAD) {
                         if (f_bias) v += bias;
                         if (f_aff) v = v * scale + shift;

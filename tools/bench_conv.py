@@ -64,6 +64,13 @@ def main():
         sw = _lib.ptr(split_ws(dev)) if not os.environ.get('BENCH_NOSPLIT') else None
         f = lambda: _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(w), None, None,
                               None, None, _lib.ptr(y), 0, sw, sp)
+        if os.environ.get('BENCH_EPI'):     # affine + residual + ReLU epilogue (a bottleneck's conv3)
+            esc = torch.rand((K,), device=dev) + 0.5
+            esh = torch.randn((K,), device=dev)
+            eres = torch.randn((d.N, d.P, d.Q, d.K), device=dev).permute(0, 3, 1, 2)
+            f = lambda: _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(w), None,
+                                  _lib.ptr(esc), _lib.ptr(esh), _lib.ptr(eres), _lib.ptr(y),
+                                  2 | 4 | 8, sw, sp)
         g = lambda: _lib.call('mrcnn_conv2d_dgrad', ctx_desc(d), _lib.ptr(gy), _lib.ptr(w),
                               _lib.ptr(gx), 0, sp)
         h = lambda: _lib.call('mrcnn_conv2d_wgrad', ctx_desc(d), _lib.ptr(x), _lib.ptr(gy),
