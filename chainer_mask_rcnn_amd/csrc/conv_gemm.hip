@@ -40,10 +40,6 @@ constexpr int BK = MRCNN_GEMM_BK;
 #define MRCNN_GEMM_SETPRIO 0
 #endif
 constexpr bool SETPRIO = MRCNN_GEMM_SETPRIO != 0;
-#ifndef MRCNN_GEMM_PINGPONG
-#define MRCNN_GEMM_PINGPONG 0   // measured slower than two free-running workgroups per CU
-#endif
-constexpr bool USE_PINGPONG = MRCNN_GEMM_PINGPONG != 0;
 // The forward-form kernel without mask staging fits 168 registers, so it runs with ONE LDS stage
 // (37 KB) and three workgroups per CU: a wave spends ~40 % of a K slice issuing MFMAs and
 // ~60 % staging (measured with s_memtime), so three interleaved waves per SIMD keep the pipe
@@ -222,33 +218,27 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
     return make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
 }
 
-// PP ("ping-pong"): a 512-thread workgroup runs TWO independent output tiles, one per group of
-// four waves, in antiphase: while one group issues its 64 MFMAs per K slice the other group
-// does everything else (wait for its global loads, write them to LDS, issue the next loads),
-// then they swap at a workgroup barrier.  Each SIMD hosts one wave of either group, so its
-// MFMA pipe always has exactly one wave feeding it and never waits for staging work; with two
-// free-running 256-thread workgroups per CU the pipe measured ~80 % busy.
-// Measured on MI355X (round 1): the strict antiphase is SLOWER (res5 3x3 fwd 110 vs 122 TF/s):
-// one wave per SIMD cannot keep the fp32 MFMA pipe as full as two interleaved waves do.  Kept
-// as a compile-time experiment (-DMRCNN_GEMM_PINGPONG=1), off by default.
+// (A "ping-pong" variant — 512-thread workgroups running two tiles in antiphase, one group
+// issuing MFMAs while the other stages — was measured slower, 110 vs 122 TFLOP/s on res5 3x3:
+// one wave per SIMD cannot keep the fp32 MFMA pipe as full as interleaved free-running waves.
+// Removed; see the history of this file.)
 // WPERM: WGRAD with position-major pixel order (GemmParams::perm_n) — a separate instantiation
 // because the natural-order kernel sits exactly at its 168-register budget.
-template <int TM, int TN, int MODE, bool MASKED, bool PP, bool WPERM = false>
-__global__ void __launch_bounds__(PP ? 512 : 256, min_blocks(TM, MODE, MASKED))
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false>
+__global__ void __launch_bounds__(256, min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
-    constexpr bool SINGLEBUF = single_buffered(TM, MODE, MASKED) && !PP;
+    constexpr bool SINGLEBUF = single_buffered(TM, MODE, MASKED);
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
     constexpr int AV = C_::A_V4, BV = C_::B_V4;
     constexpr bool HAS_MASK = MASKED;
     constexpr bool FWDLIKE = is_fwd(MODE);
-    __shared__ __attribute__((aligned(16))) float smem_all[PP ? 2 : 1][SINGLEBUF ? 1 : 2][C_::A_FLOATS + C_::B_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem_all[1][SINGLEBUF ? 1 : 2][C_::A_FLOATS + C_::B_FLOATS];
 
-    const int grp = PP ? (int)(threadIdx.x >> 8) : 0;   // ping-pong group (wave-uniform)
-    float (*smem)[C_::A_FLOATS + C_::B_FLOATS] = smem_all[grp];
-    const int tid = threadIdx.x & 255;                  // thread index within the group
+    float (*smem)[C_::A_FLOATS + C_::B_FLOATS] = smem_all[0];
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -271,7 +261,6 @@ conv_gemm_kernel(const GemmParams p)
     }
     const int split = tile / (int)gridDim.x;
     tile -= split * (int)gridDim.x;
-    if (PP) tile = 2 * tile + grp;   // a surplus tile lies beyond M: all its accesses are OOB
     const int m0 = p.m_lo + (tile / ntn) * BM;
     const int n0 = (tile % ntn) * BN;
 
@@ -628,25 +617,7 @@ conv_gemm_kernel(const GemmParams p)
         load_slice(0);
         store_slice(0);
     }
-    if (PP) {
-        // half-steps: group g computes slice kt at h = g + 2*kt and stages at h = g + 2*kt + 1
-        if (nslices > 1) load_slice(1);
-        __syncthreads();
-        const int nh = 2 * nslices + 1;
-        for (int h = 0; h < nh; ++h) {
-            const int hh = h - grp;
-            if (hh >= 0 && hh < 2 * nslices) {
-                const int kt = hh >> 1;
-                if ((hh & 1) == 0) {
-                    compute(kt & 1);
-                } else {
-                    if (kt + 1 < nslices) store_slice((kt + 1) & 1);
-                    if (kt + 2 < nslices) load_slice(kt + 2);
-                }
-            }
-            __syncthreads();
-        }
-    } else if (SINGLEBUF) {
+    if (SINGLEBUF) {
         // one LDS stage (37 KB -> three workgroups per CU, three waves per SIMD): a wave spends
         // ~40 % of a slice issuing MFMAs and ~60 % staging, so three interleaved waves are
         // needed to keep the pipe full; two barriers per slice instead of one.
@@ -1000,20 +971,15 @@ constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
 template <int TM, int TN, int MODE, bool MASKED>
 void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t s)
 {
-    if constexpr (TM == 2 && USE_PINGPONG) {
-        hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
-                           dim3((unsigned)mrcnn::ceil_div(tiles, 2), splits), dim3(512), 0, s, p);
-    } else {
-        if constexpr (MODE == WGRAD && !MASKED) {
-            if (p.perm_n > 0) {
-                hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
-                                   dim3((unsigned)tiles, splits), dim3(256), 0, s, p);
-                return;
-            }
+    if constexpr (MODE == WGRAD && !MASKED) {
+        if (p.perm_n > 0) {
+            hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
+                               dim3((unsigned)tiles, splits), dim3(256), 0, s, p);
+            return;
         }
-        hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false>),
-                           dim3((unsigned)tiles, splits), dim3(256), 0, s, p);
     }
+    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED>), dim3((unsigned)tiles, splits),
+                       dim3(256), 0, s, p);
 }
 
 inline bool is_masked(const GemmParams &p) { return p.mask_y != nullptr || p.in_scale != nullptr; }
