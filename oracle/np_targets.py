@@ -4,7 +4,8 @@ Restatement of /root/reference/chainer_mask_rcnn/models/utils/proposal_target_cr
 with the same statement order (so the global np.random stream is consumed identically),
 including the one-hot -> resize -> argmax mask-target construction (:164-177).  `cv2.resize`
 is not installable here; np_ref.resize_bilinear restates OpenCV's INTER_LINEAR rule, so the
-mask targets are "parity unpinned" (the sampling / labels / locs need only NumPy).
+resize underneath is "parity unpinned"; the class as a whole is pinned to the reference's own
+class body by tests/golden/proposal_target_creator.npz (oracle/gen_golden.py section 6).
 """
 import numpy as np
 
