@@ -87,6 +87,8 @@ SIGNATURES = {
     'mrcnn_softmax': (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp]),
     'mrcnn_sgd_momentum_wd': (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
                                       c_vp]),
+    'mrcnn_sgd_momentum_wd_ex': (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
+                                         c_int, c_vp]),
     'mrcnn_prepare_image': (c_int, [c_vp, c_int, c_int, c_int, c_int, ctypes.c_double,
                                     ctypes.POINTER(c_f32), c_vp, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_vp]),

@@ -188,7 +188,8 @@ __global__ void avgpool_bwd_kernel(const float *__restrict__ gy, float *__restri
 }
 
 // ---- MomentumSGD + WeightDecay -----------------------------------
-__global__ void sgd_kernel(float *__restrict__ p, const float *__restrict__ g,
+template <bool ZERO_GRAD>
+__global__ void sgd_kernel(float *__restrict__ p, float *__restrict__ g,
                            float *__restrict__ v, int64_t n, float lr, float momentum, float wd,
                            float grad_scale)
 {
@@ -205,12 +206,14 @@ __global__ void sgd_kernel(float *__restrict__ p, const float *__restrict__ g,
         pp.x += vv.x; pp.y += vv.y; pp.z += vv.z; pp.w += vv.w;
         reinterpret_cast<float4 *>(v)[i] = vv;
         reinterpret_cast<float4 *>(p)[i] = pp;
+        if (ZERO_GRAD) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const float vv = momentum * v[i] - lr * (g[i] * grad_scale + wd * p[i]);
         v[i] = vv;
         p[i] += vv;
+        if (ZERO_GRAD) g[i] = 0.f;
     }
 }
 
@@ -347,15 +350,28 @@ extern "C" int mrcnn_avgpool_bwd(const float *gy, float *gx, int R, int HW, int 
     return mrcnn::check_launch("avgpool_bwd");
 }
 
-extern "C" int mrcnn_sgd_momentum_wd(float *p, const float *g, float *v, int64_t n, float lr,
-                                     float momentum, float wd, float grad_scale, void *stream)
+extern "C" int mrcnn_sgd_momentum_wd_ex(float *p, float *g, float *v, int64_t n, float lr,
+                                        float momentum, float wd, float grad_scale, int zero_grad,
+                                        void *stream)
 {
     MRCNN_REQUIRE(n >= 0, "sgd: n < 0");
     if (n == 0) return 0;
     MRCNN_REQUIRE(p && g && v, "sgd: null pointer");
     MRCNN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(v), "sgd: arenas must be 16-byte aligned");
-    mrcnn::ProfScope prof(mrcnn::PROF_SGD, 0., 20.0 * (double)n, mrcnn::as_stream(stream));
-    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, mrcnn::as_stream(stream),
-                       p, g, v, n, lr, momentum, wd, grad_scale);
+    mrcnn::ProfScope prof(mrcnn::PROF_SGD, 0., (zero_grad ? 24.0 : 20.0) * (double)n,
+                          mrcnn::as_stream(stream));
+    if (zero_grad)
+        hipLaunchKernelGGL(sgd_kernel<true>, dim3(grid_for(n / 4 + 1)), dim3(256), 0,
+                           mrcnn::as_stream(stream), p, g, v, n, lr, momentum, wd, grad_scale);
+    else
+        hipLaunchKernelGGL(sgd_kernel<false>, dim3(grid_for(n / 4 + 1)), dim3(256), 0,
+                           mrcnn::as_stream(stream), p, g, v, n, lr, momentum, wd, grad_scale);
     return mrcnn::check_launch("sgd");
+}
+
+extern "C" int mrcnn_sgd_momentum_wd(float *p, const float *g, float *v, int64_t n, float lr,
+                                     float momentum, float wd, float grad_scale, void *stream)
+{
+    return mrcnn_sgd_momentum_wd_ex(p, const_cast<float *>(g), v, n, lr, momentum, wd, grad_scale, 0,
+                                    stream);
 }

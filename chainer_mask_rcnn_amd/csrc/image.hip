@@ -7,7 +7,10 @@
 //                  resize to the box, threshold at 0.5, paste into the image.
 // cv2 is not installable in the build container; both kernels restate OpenCV's INTER_LINEAR
 // float path (src = (float)((dst + 0.5) * scale - 0.5), floor, clamp to the border, horizontal
-// then vertical blend) exactly as oracle/np_infer.py does.  Built with -ffp-contract=off.
+// then vertical blend) exactly as oracle/np_infer.py does; uint8 sources take OpenCV's 8-bit
+// fixed-point path (11-bit coefficients, result rounded to uint8 before the mean is subtracted),
+// which is what cv2.resize runs for the decoded images MaskRCNNTransform feeds.
+// Built with -ffp-contract=off.
 #include "common.h"
 
 namespace {
@@ -43,6 +46,25 @@ __global__ void prepare_kernel(const T *__restrict__ src, int C, int H, int W, d
     const Lin ly = lin_coord(y, inv_scale, H);
     const Lin lx = lin_coord(flip_x ? outW - 1 - x : x, inv_scale, W);
     float *o = dst + (((int64_t)n * dstH + y) * dstW + x) * C;
+    if constexpr (sizeof(T) == 1) {
+        // OpenCV 8-bit path (imgproc/resize.cpp: HResizeLinear<uchar,int,short> +
+        // VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>), see
+        // oracle/np_infer.py:cv_resize_linear_u8.  Integer arithmetic: bit-exact vs the oracle.
+        float fy = (float)(((double)y + 0.5) * inv_scale - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= (float)sy;                                     // vertical weight is NOT clamped
+        const int y0 = min(max(sy, 0), H - 1), y1 = min(max(sy + 1, 0), H - 1);
+        const int a0 = __float2int_rn((1.f - lx.t) * 2048.f), a1 = __float2int_rn(lx.t * 2048.f);
+        const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+        for (int c = 0; c < C; ++c) {
+            const T *p = src + (int64_t)c * H * W;
+            const int d0 = (int)p[y0 * W + lx.i0] * a0 + (int)p[y0 * W + lx.i1] * a1;
+            const int d1 = (int)p[y1 * W + lx.i0] * a0 + (int)p[y1 * W + lx.i1] * a1;
+            const int v = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2;
+            o[c] = (float)min(max(v, 0), 255) - (c == 0 ? m0 : (c == 1 ? m1 : m2));
+        }
+        return;
+    }
     for (int c = 0; c < C; ++c) {
         const T *p = src + (int64_t)c * H * W;
         const float top = (float)p[ly.i0 * W + lx.i0] * (1.f - lx.t) + (float)p[ly.i0 * W + lx.i1] * lx.t;

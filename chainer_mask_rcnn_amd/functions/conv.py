@@ -17,8 +17,16 @@ from ._layout import nhwc, empty_nhwc
 
 
 def _direct_grad(p):
-    """A parameter whose ``.grad`` is a preallocated arena view is written in place."""
-    return getattr(p, '_direct_grad', False) and p.grad is not None
+    """Claim the right to WRITE ``p``'s gradient in place: true for an arena-backed parameter
+    (optimizers.ParamArena) whose arena view is intact and that has not received a gradient yet
+    in this step.  Otherwise the caller returns a fresh tensor and autograd accumulates it."""
+    arena = getattr(p, '_arena', None)
+    if arena is None:
+        return False
+    if arena.claim(p):
+        return True
+    join_wgrad_stream(p.device)      # an earlier in-place write may still be queued there
+    return False
 
 
 def conv_out_size(size, k, s, p):
@@ -103,7 +111,7 @@ class _Conv2dFn(torch.autograd.Function):
         gx = gW = gb = None
         if need_w:
             W = ctx.W_param
-            if _direct_grad(W) and USE_WGRAD_STREAM:
+            if USE_WGRAD_STREAM:
                 gW = _wgrad_raw(d, x, g, W, None, None, wgrad_stream(gy.device))
             else:
                 direct = _direct_grad(W)

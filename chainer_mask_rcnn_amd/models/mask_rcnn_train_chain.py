@@ -112,14 +112,22 @@ class MaskRCNNTrainChain(torch.nn.Module):
         if hasattr(atc, 'prepare') and hasattr(atc, 'finish'):
             atc_jobs = [_pool().submit(atc.prepare, bbox, anchor_h, img_size) for bbox in bboxes]
         pc = getattr(self.mask_rcnn.rpn, 'proposal_layer', None)
-        if pc is not None and hasattr(pc, 'keep_host_copy'):
-            pc.keep_host_copy = True       # proposals also as host arrays, same synchronisation
-        rpn_locs, rpn_scores, rois, roi_indices, anchor = self.mask_rcnn.rpn(
-            features, img_size, scales)
+        has_flag = pc is not None and hasattr(pc, 'keep_host_copy')
+        prev_flag = pc.keep_host_copy if has_flag else None
+        try:
+            if has_flag:
+                pc.keep_host_copy = True   # proposals also as host arrays, same synchronisation
+            rpn_locs, rpn_scores, rois, roi_indices, anchor = self.mask_rcnn.rpn(
+                features, img_size, scales)
+        finally:
+            if has_flag:                   # predict() / eval calls keep their single D2H read
+                pc.keep_host_copy = prev_flag
 
         # proposal targets: host-side sampling, exactly as the reference (:126-146)
         mark('extractor+rpn queued')
         host_rois = getattr(pc, 'last_host_rois', None) if pc is not None else None
+        if host_rois is not None:
+            pc.last_host_rois = None       # consumed
         if host_rois is None:
             rois_h = rois.cpu().numpy()
             roi_indices_h = roi_indices.cpu().numpy()

@@ -80,7 +80,14 @@ class ProposalTargetCreator(object):
     def mask_targets(self, job, mask):
         """14x14 mask targets for the foreground RoIs; background rows stay -1 (:160-177).
         The reference one-hot encodes the {0,1} crop, resizes both channels with bilinear
-        weights (which sum to 1) and takes the argmax, i.e. foreground probability > 0.5."""
+        weights (which sum to 1) and takes the argmax, i.e. foreground probability > 0.5.
+
+        Deviation (documented): a foreground RoI whose rounded box is empty (zero height or
+        width after ``np.round``) makes the reference raise inside ``gt_roi_mask_i.max()`` /
+        ``cv2.resize`` on an empty crop; here its mask target is all background (0).  Such a
+        RoI needs IoU >= 0.5 with a ground-truth box while being < 0.5 px wide — it cannot
+        occur with COCO boxes (>= 1 px) and is covered by
+        tests/test_targets_cpu.py::test_degenerate_crop_is_all_background."""
         n, n_fg, boxes, gt_index = job
         M = self.mask_size
         gt_roi_mask = -np.ones((n, M, M), dtype=np.int32)

@@ -302,6 +302,13 @@ int mrcnn_softmax(const float *x, int ldx, float *y, int ldy, int R, int ncls,
 int mrcnn_sgd_momentum_wd(float *p, const float *g, float *v, int64_t n, float lr,
                           float momentum, float wd, float grad_scale,
                           void *stream);
+/* Same update; with zero_grad != 0 the gradient arena is cleared in the same pass (chainer's
+ * cleargrads() before the next backward, examples/train_common.py:226-231 via
+ * StandardUpdater.update_core): a parameter whose backward does not run in the next step then
+ * contributes a zero gradient instead of a stale one. */
+int mrcnn_sgd_momentum_wd_ex(float *p, float *g, float *v, int64_t n, float lr,
+                             float momentum, float wd, float grad_scale, int zero_grad,
+                             void *stream);
 
 /* Per-class `prob > thresh` filter + stable descending sort + gather, all foreground
  * classes in one launch: the first half of MaskRCNN._suppress (models/mask_rcnn.py:178-202).

@@ -291,6 +291,11 @@ def main():
             sy, sx = 1. / fy, 1. / fx
         else:
             (out_w, out_h), sy, sx = dsize, None, None
+        if img.dtype == np.uint8:      # cv2.resize dispatches on depth: 8-bit fixed-point path
+            out = np.stack([np_infer.cv_resize_linear_u8(np.ascontiguousarray(chans[..., c]),
+                                                         int(out_h), int(out_w), sy, sx)
+                            for c in range(chans.shape[-1])], axis=-1)
+            return out[..., 0] if img.ndim == 2 else out
         out = np.stack([np_infer.cv_resize_linear(chans[..., c].astype(np.float32), int(out_h),
                                                   int(out_w), sy, sx)
                         for c in range(chans.shape[-1])], axis=-1)

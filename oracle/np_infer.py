@@ -93,8 +93,48 @@ def cv_resize_linear(img, out_h, out_w, scale_y=None, scale_x=None):
     return (top * (one - ty)[:, None] + bot * ty[:, None]).astype(np.float32)
 
 
+def _cv_round_short(v):
+    """saturate_cast<short>(float): cvRound = round half to even."""
+    return np.clip(np.rint(np.asarray(v, np.float32)), -32768, 32767).astype(np.int32)
+
+
+def cv_resize_linear_u8(img, out_h, out_w, scale_y=None, scale_x=None):
+    """cv2.resize(INTER_LINEAR) of an (h, w) uint8 image: OpenCV's 8-bit FIXED-POINT path
+    (imgproc/resize.cpp, resizeGeneric_ + HResizeLinear<uchar,int,short> +
+    VResizeLinear<uchar,int,short,FixedPtCast<.., 22>>), restated from the published source:
+
+      horizontal: fx as in the float path (clamped to the border with fx = 0),
+                  a = saturate_cast<short>({1 - fx, fx} * 2048),   D = S[sx]*a0 + S[sx+1]*a1   (int)
+      vertical:   fy = (float)((dy + .5)*scale - .5) - floor(..)  (NOT clamped), the two source
+                  rows clipped to [0, h-1],  b = saturate_cast<short>({1 - fy, fy} * 2048),
+                  dst = uchar((((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2)
+
+    (the exact 2x down-scale, which OpenCV reroutes to INTER_AREA, is not special-cased: the
+    min_size / max_size rule of MaskRCNN.prepare never scales by exactly 1/2 on COCO sizes up).
+    cv2 is not installable here: "parity unpinned"."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 2
+    h, w = img.shape
+    x0, x1, tx = _cv_axis(out_w, w, w / float(out_w) if scale_x is None else scale_x)
+    a0, a1 = _cv_round_short((np.float32(1) - tx) * np.float32(2048)), _cv_round_short(tx * np.float32(2048))
+    sy = h / float(out_h) if scale_y is None else scale_y
+    d = np.arange(out_h, dtype=np.float64)
+    fy = ((d + 0.5) * sy - 0.5).astype(np.float32)
+    s = np.floor(fy).astype(np.int64)
+    fy = (fy - s.astype(np.float32)).astype(np.float32)
+    y0, y1 = np.clip(s, 0, h - 1), np.clip(s + 1, 0, h - 1)
+    b0, b1 = _cv_round_short((np.float32(1) - fy) * np.float32(2048)), _cv_round_short(fy * np.float32(2048))
+    src = img.astype(np.int32)
+    D = src[:, x0] * a0[None, :] + src[:, x1] * a1[None, :]          # (h, out_w) int32
+    D0, D1 = D[y0] >> 4, D[y1] >> 4
+    out = (((b0[:, None] * D0) >> 16) + ((b1[:, None] * D1) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def prepare(img, mean, min_size, max_size):
-    """MaskRCNN.prepare for one CHW image (mask_rcnn.py:152-176) -> (prepared CHW f32, scale)."""
+    """MaskRCNN.prepare for one CHW image (mask_rcnn.py:152-176) -> (prepared CHW f32, scale).
+    uint8 images take OpenCV's 8-bit fixed-point resize (result rounded to uint8 before the
+    mean is subtracted), float images the float path — as cv2.resize dispatches on depth."""
     _, H, W = img.shape
     scale = 1.
     if min_size:
@@ -102,8 +142,12 @@ def prepare(img, mean, min_size, max_size):
     if max_size and scale * max(H, W) > max_size:
         scale = max_size / max(H, W)
     out_h, out_w = int(np.round(H * scale)), int(np.round(W * scale))   # cvRound(src * f)
-    out = np.stack([cv_resize_linear(img[c].astype(np.float32), out_h, out_w, 1. / scale, 1. / scale)
-                    for c in range(img.shape[0])])
+    if np.asarray(img).dtype == np.uint8:
+        out = np.stack([cv_resize_linear_u8(img[c], out_h, out_w, 1. / scale, 1. / scale)
+                        for c in range(img.shape[0])]).astype(np.float32)
+    else:
+        out = np.stack([cv_resize_linear(img[c].astype(np.float32), out_h, out_w, 1. / scale, 1. / scale)
+                        for c in range(img.shape[0])])
     return (out - np.asarray(mean, np.float32).reshape(-1, 1, 1)).astype(np.float32), scale
 
 

@@ -106,3 +106,16 @@ def test_proposal_target_creator_pinned_to_reference_class(golden_dir):
     s_roi, loc, lab, job = ptc.sample(d['roi'], d['bbox'], d['label'])
     assert np.random.randint(0, 1 << 30) == int(d['next_randint'])   # mask_targets draws nothing
     assert np.array_equal(ptc.mask_targets(job, mask), d['gt_roi_mask'])
+
+
+def test_degenerate_crop_is_all_background():
+    """Documented deviation (proposal_target_creator.mask_targets): a foreground RoI whose
+    rounded box is empty makes the reference raise on the empty crop; the split job returns an
+    all-background (0) mask target for it and -1 rows for the background RoIs."""
+    H, W = 64, 64
+    mask = np.ones((1, H, W), np.int32)
+    ptc = ProposalTargetCreator(n_sample=4)
+    boxes = np.array([[10, 10, 10, 30], [5, 5, 25, 25]], np.int32)   # first: zero height
+    out = ptc.mask_targets((4, 2, boxes, np.array([0, 0])), mask)
+    assert out.shape == (4, 14, 14) and out.dtype == np.int32
+    assert (out[0] == 0).all() and (out[1] == 1).all() and (out[2:] == -1).all()
