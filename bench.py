@@ -2,7 +2,8 @@
 """bench.py — images/sec of one Mask R-CNN ResNet50-C4 TRAIN STEP on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: either under a launcher — python -m torch.distributed.run --nproc-per-node N ...
+     bench.py --gpus N ... — or bare: bench.py then starts its own N ranks, one per GPU)
 
 A "step" is one pass of the hot path over one synthetic batch: forward (ResNet-C4
 extractor, RPN, device ProposalCreator, host target creators, ROIAlign, res5 head, five
@@ -61,7 +62,7 @@ def synthetic_batch(rng, batch, H, W, n_gt=8, n_fg_class=80):
     return imgs, bboxes, labels, masks, scales
 
 
-def build_trainer(n_layers, device, world, lr_batch, force_dp=False):
+def build_trainer(n_layers, device, world, lr_batch, force_dp=False, bucket_bytes=16 << 20):
     import chainer_mask_rcnn_amd as cmr
     from chainer_mask_rcnn_amd import optimizers, parallel
     # examples/coco/train.py:36-38 + examples/train_common.py:160-169
@@ -85,7 +86,7 @@ def build_trainer(n_layers, device, world, lr_batch, force_dp=False):
     stabilise_synthetic_weights(model)
     sync = None
     if world > 1 or force_dp:
-        sync = parallel.DataParallelGradSync(opt)
+        sync = parallel.DataParallelGradSync(opt, bucket_bytes=bucket_bytes)
     return model, chain, opt, sync
 
 
@@ -231,7 +232,7 @@ def bench_infer(args, device, rank):
         conv = {k: v for k, v in prof.items() if k.startswith('conv_gemm')}
         gflop = sum(v['flops'] for v in conv.values()) / 1e9
         ms = sum(v['total_ms'] for v in conv.values())
-        print(json.dumps(dict(
+        emit_json(dict(
             metric='images/sec inference, ResNet%d-C4 Mask R-CNN, 8x1024x1024' % args.layers,
             value=round(args.steps * batch / elapsed, 3), unit='images/sec', n_gpus=1,
             steps=args.steps, warmup=args.warmup,
@@ -248,7 +249,46 @@ def bench_infer(args, device, rank):
                           traffic=None,
                           kernels={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
                                            launches_per_step=v['launches'] / args.steps)
-                                   for k, v in prof.items()}))))
+                                   for k, v in prof.items()})))
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+_REAL_STDOUT = None
+
+
+def emit_json(obj):
+    """The ONE JSON line, written to the process's real stdout (see main())."""
+    line = (json.dumps(obj) + '\n').encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, line)
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU ourselves
+    (torch.distributed.run, rendezvous on 127.0.0.1) and pass their output through."""
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit('bench.py --gpus %d: only %d ROCm device(s) visible on this node; '
+                         'one process per GPU is required (no oversubscription)'
+                         % (args.gpus, n_dev))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -272,18 +312,34 @@ def main():
                     help="'train' = BASELINE configs[1..3] (the headline metric); 'infer' = "
                          "configs[4]: inference-only 8x1024x1024, 1000 proposals/img")
     ap.add_argument('--force-dp', action='store_true',
-                    help='create a 1-rank RCCL group and run the data-parallel gradient path')
+                    help='create a 1-rank RCCL communicator and run the data-parallel gradient path')
+    ap.add_argument('--rotate-batches', type=int, default=4,
+                    help='after the resident-batch measurement, time the same number of steps '
+                         'over K pre-generated host batches with the image upload inside the '
+                         'timed region (the reference converter uploads every iteration, '
+                         'examples/train_common.py:219-225); 0 = skip')
+    ap.add_argument('--bucket-mb', type=float, default=16.0,
+                    help='gradient all-reduce bucket size (data-parallel runs)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args)
+    # stdout carries rank 0's ONE JSON line and nothing else: native libraries (gloo's
+    # connection notice, RCCL's version banner) write to fd 1 too, so fd 1 points at stderr for
+    # the whole run and the JSON line goes to a saved duplicate of the real stdout
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     from chainer_mask_rcnn_amd import parallel, _lib
     rank, world, local = parallel.init_from_env()
-    if args.force_dp and world == 1 and not dist.is_initialized():
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=0, world_size=1)
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.force_dp and world == 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
+        dist.init_process_group('gloo', rank=0, world_size=1)    # control plane (unique id store)
     # one process per GPU shares the host with its peers: keep torch's CPU thread pool (used
     # only for tiny host-side tensor plumbing) from oversubscribing the cores
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(1, 2 * world))))
@@ -304,9 +360,11 @@ def main():
 
     rng = np.random.RandomState(rank)
     imgs, bboxes, labels, masks, scales = synthetic_batch(rng, args.batch, args.height, args.width)
+    parallel_bucket_bytes = int(args.bucket_mb * 2 ** 20)
     model, chain, opt, sync = build_trainer(args.layers, device, world,
                                             args.lr_batch or args.batch * world,
-                                            force_dp=args.force_dp)
+                                            force_dp=args.force_dp,
+                                            bucket_bytes=parallel_bucket_bytes)
     imgs_d = torch.tensor(imgs, device=device).contiguous(memory_format=torch.channels_last)
 
     def step():
@@ -314,9 +372,16 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if sync is not None and world > 1:
+            sync.exchange.barrier()               # RCCL all-reduce + device synchronise
             torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # control plane (gloo)
+        return float(t.item())
 
     for _ in range(args.warmup):
         loss = step()
@@ -327,6 +392,8 @@ def main():
         # kernel symbol: half of the GPU time); every other kind just counts launches / flops /
         # bytes.  --profile-all times everything.
         lib.mrcnn_profile_enable(1 if args.profile_all else 2)
+    if sync is not None:
+        sync.exchange.timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -334,12 +401,41 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = {} if args.no_profile else profile_summary()
     lib.mrcnn_profile_enable(0)
+    bucket_times = None
+    if sync is not None:
+        bucket_times = sync.exchange.bucket_times(len(sync.buckets.bounds))
+        sync.exchange.timing(False)
     n_rois = chain.last_targets['n_rois']
     loss_val = float(loss.item())
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
+
+    # ---- second measurement: rotating host batches, image upload inside the timed region ----
+    rotating = None
+    if args.rotate_batches > 0:
+        K = args.rotate_batches
+        host = [(imgs, bboxes, labels, masks, scales)]
+        for _ in range(K - 1):
+            host.append(synthetic_batch(rng, args.batch, args.height, args.width))
+        pinned = [torch.from_numpy(np.ascontiguousarray(h[0])).pin_memory() for h in host]
+
+        def rot_step(k):
+            b = host[k % K]
+            x = pinned[k % K].to(device, non_blocking=True)       # H2D: 25.6 MB per batch of 2
+            return opt.update(chain, x, b[1], b[2], b[3], b[4])
+
+        for k in range(min(K, max(2, args.warmup))):
+            rot_step(k)
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            loss_r = rot_step(k)
+        fence()
+        el_r = max_over_ranks(time.perf_counter() - t0)
+        rotating = dict(value=round(args.steps * args.batch * world / el_r, 3), unit='images/sec',
+                        ms_per_step=round(el_r / args.steps * 1e3, 3), batches=K,
+                        input='rotating+h2d: %d pre-generated pinned host batches, image upload '
+                              '(non_blocking copy on the compute stream) inside the timed region' % K,
+                        loss=round(float(loss_r.item()), 5))
 
     if rank == 0:
         global_batch = args.batch * world
@@ -366,31 +462,48 @@ def main():
                                              gbs=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1),
                                              launches_per_step=v['launches'] / args.steps)
                                      for k, v in timed.items()})
+        cfg_index = 1 if world == 1 else 2
+        if args.layers == 101:
+            cfg_index = 3
+        config = dict(
+            workload='BASELINE configs[%d]%s: ResNet%d-C4 Mask R-CNN train step '
+                     '(fwd+bwd%s+SGD), batch %dx%dx%d fp32 per GPU, %d sampled RoIs/step/GPU'
+                     % (cfg_index, '' if (cfg_index != 3 or world == 8) else
+                        ' (per-GPU part on %d GPU%s)' % (world, 's' if world > 1 else ''),
+                        args.layers, '+RCCL all-reduce' if sync is not None else '',
+                        args.batch, args.height, args.width, n_rois),
+            input='resident', global_batch=global_batch, rois_per_image=n_rois // args.batch,
+            parallelism='dp%d' % world,
+            loss=round(loss_val, 5) if np.isfinite(loss_val) else None,
+            # reference algorithm (mask branch on all 512 RoIs/img)
+            reference_gflop_per_image=TRAIN_GFLOP_PER_IMAGE[args.layers],
+            # what the GEMM kernels executed (the mask branch runs on foreground
+            # RoIs only: identical loss and gradients)
+            executed_gemm_gflop_per_image=round(gemm_gflop / args.steps / args.batch, 1)
+            if prof else None,
+            gemm_tflops=round(gemm_gflop / gemm_ms, 2) if prof and gemm_all_timed else None)
+        if sync is not None:
+            coll = sync.describe()
+            if bucket_times is not None:
+                coll['allreduce_ms_per_step'] = [round(ms / args.steps, 3) for ms, _, _ in bucket_times]
+                coll['allreduce_gbs'] = [round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None
+                                         for ms, by, _ in bucket_times]
+            config['collective'] = coll
         out = dict(
             metric='images/sec train step, ResNet50-C4 Mask R-CNN, COCO 800x1333'
             if args.layers == 50 else 'images/sec train step, ResNet101-C4 Mask R-CNN, COCO 800x1333',
             value=round(value, 3), unit='images/sec', n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
-            data='synthetic',
-            config=dict(workload='BASELINE configs[1]: ResNet%d-C4 Mask R-CNN train step '
-                        '(fwd+bwd+SGD), batch %dx%dx%d fp32 per GPU, %d sampled RoIs/step/GPU'
-                        % (args.layers, args.batch, args.height, args.width, n_rois),
-                        global_batch=global_batch, rois_per_image=n_rois // args.batch,
-                        parallelism='dp%d' % world,
-                        loss=round(loss_val, 5) if np.isfinite(loss_val) else None,
-                        # reference algorithm (mask branch on all 512 RoIs/img)
-                        reference_gflop_per_image=TRAIN_GFLOP_PER_IMAGE[args.layers],
-                        # what the GEMM kernels executed (the mask branch runs on foreground
-                        # RoIs only: identical loss and gradients)
-                        executed_gemm_gflop_per_image=round(gemm_gflop / args.steps / args.batch, 1)
-                        if prof else None,
-                        gemm_tflops=round(gemm_gflop / gemm_ms, 2) if prof and gemm_all_timed
-                        else None),
-            roofline=roofline)
+            data='synthetic', config=config, roofline=roofline)
+        if rotating is not None:
+            out['rotating_h2d'] = rotating
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+        emit_json(out)
+    if sync is not None and hasattr(sync.exchange, 'close'):
+        torch.cuda.synchronize()
+        sync.exchange.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -89,6 +89,18 @@ SIGNATURES = {
                                       c_vp]),
     'mrcnn_sgd_momentum_wd_ex': (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
                                          c_int, c_vp]),
+    'mrcnn_allreduce_unique_id': (c_int, [c_vp]),
+    'mrcnn_allreduce_init': (c_int, [c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
+    'mrcnn_allreduce_destroy': (c_int, [c_vp]),
+    'mrcnn_allreduce_info': (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                     ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
+    'mrcnn_allreduce_bucket': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
+    'mrcnn_allreduce_wait': (c_int, [c_vp, c_vp]),
+    'mrcnn_allreduce_broadcast': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
+    'mrcnn_allreduce_timing': (c_int, [c_vp, c_int]),
+    'mrcnn_allreduce_bucket_times': (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(c_i64)]),
     'mrcnn_prepare_image': (c_int, [c_vp, c_int, c_int, c_int, c_int, ctypes.c_double,
                                     ctypes.POINTER(c_f32), c_vp, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_vp]),

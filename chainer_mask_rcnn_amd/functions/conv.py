@@ -362,6 +362,11 @@ def wgrad_stream(device):
     return _side_streams[key]
 
 
+def wgrad_stream_if_used(device):
+    """The weight-gradient side stream of ``device`` if one has been created, else None."""
+    return _side_streams.get(str(device))
+
+
 def join_wgrad_stream(device=None):
     """Make the current stream wait for every weight gradient queued on the side stream
     (call before reading gradients: optimizer step, all-reduce)."""
@@ -482,9 +487,12 @@ PRETRANSPOSE_FILTERS = False
 class _StageFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, strides, proj, *params):
+    def forward(ctx, x, strides, proj, poll, *params):
         """``strides[i]`` / ``proj[i]``: conv1(/conv4) stride and has-projection flag of block
-        i; ``params``: per block W1,s1,b1,W2,s2,b2,W3,s3,b3 (+ W4,s4,b4 when proj[i])."""
+        i; ``poll``: optional callable invoked during backward at the stage's entry and after
+        every block's weight gradients have been queued (parallel.DataParallelGradSync launches
+        the gradient buckets that are complete); ``params``: per block W1,s1,b1,W2,s2,b2,W3,s3,b3
+        (+ W4,s4,b4 when proj[i])."""
         _lib.require_device(x, params[0])
         x = nhwc(x)
         blocks, saved, pos = [], [x], 0
@@ -511,6 +519,7 @@ class _StageFn(torch.autograd.Function):
             h = y
         ctx.blocks = blocks
         ctx.proj = tuple(proj)
+        ctx.poll = poll
         ctx.save_for_backward(*saved)
         ctx.wT = None
         if PRETRANSPOSE_FILTERS and any(ctx.needs_input_grad):
@@ -534,6 +543,9 @@ class _StageFn(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         ng = ctx.needs_input_grad
         grads = [None] * len(ng)
+        poll = ctx.poll
+        if poll is not None:
+            poll()                 # everything upstream of this stage has queued its gradients
         # unpack per-block activations
         acts, pos, xin = [], 1, saved[0]
         for pj in ctx.proj:
@@ -565,7 +577,7 @@ class _StageFn(torch.autograd.Function):
             x, h1, h2, y, s1, s2, s3, s4 = acts[i]
             (d1, d2, d3, d4), (W1, W2, W3, W4), p0 = ctx.blocks[i]
             wT = stage_wT[i]
-            base = 3 + p0                      # index of W1 among the forward inputs
+            base = 4 + p0                      # index of W1 among the forward inputs
             first = i == 0
             # what the gradient leaving this block must be masked with: the previous block's
             # output ReLU (= this block's input); the stage input belongs to someone else
@@ -582,6 +594,8 @@ class _StageFn(torch.autograd.Function):
                              wT=wT.get('2'))
             if ng[base]:
                 grads[base] = _wgrad_raw(d1, x, gh1, W1, None, None, side)
+            if poll is not None:
+                poll()             # this block's weight gradients are queued
             if first and not ng[0]:
                 break
             if W4 is None:
@@ -601,7 +615,7 @@ class _StageFn(torch.autograd.Function):
         return tuple(grads)
 
 
-def building_block(x, blocks, first_stride=None):
+def building_block(x, blocks, first_stride=None, poll=None):
     """A chain of Bottleneck links (chainer BuildingBlock) as one fused autograd node."""
     strides, proj, params = [], [], []
     for i, b in enumerate(blocks):
@@ -611,4 +625,4 @@ def building_block(x, blocks, first_stride=None):
                    b.conv3.W, b.bn3.W, b.bn3.b]
         if b.projection:
             params += [b.conv4.W, b.bn4.W, b.bn4.b]
-    return _StageFn.apply(x, tuple(strides), tuple(proj), *params)
+    return _StageFn.apply(x, tuple(strides), tuple(proj), poll, *params)

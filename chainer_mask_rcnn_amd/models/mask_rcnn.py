@@ -249,12 +249,14 @@ class MaskRCNN(torch.nn.Module):
         masks = self._to_masks(bboxes, labels, scores, roi_masks, sizes)
         return bboxes, masks, labels, scores
 
-    def predict_prepared(self, x, scales, sizes, masks_to_host=True):
+    def predict_prepared(self, x, scales, sizes, masks_to_host=True, return_intermediates=False):
         """The device part of ``predict`` (:311-335) on an already prepared, zero-padded
         batch x (N,3,H,W) with per-image ``scales`` and original ``sizes`` (H,W).
 
         Returns (bboxes, roi_mask_logits, labels, scores): per-image lists of host arrays;
-        roi_mask_logits[i] is (D_i, n_fg_class, 14, 14)."""
+        roi_mask_logits[i] is (D_i, n_fg_class, 14, 14).  ``return_intermediates`` appends a
+        dict with the head outputs the detections were computed from (``roi_cls_locs``,
+        ``roi_scores``, ``rois``, ``roi_indices`` device tensors, ``feature_shape``)."""
         was_training = self.training
         self.eval()
         try:
@@ -299,4 +301,8 @@ class MaskRCNN(torch.nn.Module):
                 roi_masks = [m.cpu().numpy() for m in roi_masks]
         finally:
             self.train(was_training)
+        if return_intermediates:
+            return bboxes, roi_masks, labels, scores, dict(
+                roi_cls_locs=roi_cls_locs, roi_scores=roi_scores, rois=rois,
+                roi_indices=roi_indices, feature_shape=tuple(h.shape))
         return bboxes, roi_masks, labels, scores

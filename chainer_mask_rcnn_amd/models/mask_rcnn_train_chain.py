@@ -220,5 +220,6 @@ class MaskRCNNTrainChain(torch.nn.Module):
                        'loss': loss.detach()}
         mark('losses queued')
         self.last_targets = {'sample_rois': sample_rois, 'gt_roi_labels': gt_roi_labels,
+                             'gt_roi_masks': gt_roi_masks, 'gt_rpn_labels': gt_rpn_labels,
                              'n_rois': int(sample_rois.shape[0])}
         return loss

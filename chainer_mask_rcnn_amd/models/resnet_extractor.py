@@ -95,12 +95,16 @@ class BuildingBlock(torch.nn.Module):
             name = 'b{}'.format(i + 1)
             setattr(self, name, Bottleneck(out_ch, mid_ch, out_ch))
             self._names.append(name)
+        # optional callable polled during the fused stage's backward (entry + after every
+        # block): parallel.DataParallelGradSync launches completed gradient buckets from it
+        self.grad_poll = None
 
     def forward(self, x, first_stride=None):
         """``first_stride`` overrides the stride of block ``a`` (used by the RoI head when the
         stride-2 subsampling has already been done by the pooling op)."""
         if self.fused_stage:
-            return F.building_block(x, [getattr(self, n) for n in self._names], first_stride)
+            return F.building_block(x, [getattr(self, n) for n in self._names], first_stride,
+                                    poll=self.grad_poll)
         for name in self._names:
             if name == 'a' and first_stride is not None:
                 x = self.a(x, stride=first_stride)
@@ -144,8 +148,8 @@ class ResNetExtractorBase(torch.nn.Module):
         if not remove_layers or 'res5' not in remove_layers:
             self.res5 = BuildingBlock(n[3], 1024, 512, 2048, 2)
         self._stem_cache = None
-        # optional {stage name: tensor hook}; parallel.DataParallelGradSync uses 'res3' to
-        # learn that res4's gradients are complete
+        # optional {stage name: tensor hook}, fired when backward has passed the stage's output
+        # (parallel.DataParallelGradSync polls its gradient buckets there)
         self.stage_hooks = {}
 
     def _stem(self, x):

@@ -2,121 +2,331 @@
 
 Replaces ChainerMN's 'hierarchical' communicator + multi-node optimizer
 (/root/reference/examples/train_common.py:97-103,178): gradients are
-averaged across ranks before the optimizer step and rank-0 weights are broadcast once.
+averaged across ranks before the optimizer step and rank-0 parameters are broadcast once.
 
-MI355X-first design: the gradient arena of ``optimizers.ParamArena`` is laid out in the
-order backward produces gradients (head, RPN, res4, res3), so each bucket is ONE
-contiguous slice.  A bucket's all-reduce is issued (async, on RCCL's own stream) as soon
-as backward has passed the activation that closes the bucket, and overlaps with the
-remaining ResNet backward; the compute stream waits only right before the SGD launch.
-xGMI is point-to-point (7 links per GPU): a few large messages (tens of MB each) keep
-every link's ring segment bandwidth-bound instead of latency-bound.
-The sum is scaled by 1/world_size inside the SGD kernel (no extra pass).
+MI355X-first design
+* The gradient arena of ``optimizers.ParamArena`` is laid out in the order backward produces
+  gradients (mask head, FCs, res5.b2, res5.b1, res5.a, RPN, res4 ..., res3 ...), so every
+  bucket is ONE contiguous slice.  Buckets are cut at layer-block boundaries, ~16 MB each
+  (xGMI is point-to-point, 7 links per GPU: tens-of-MB messages keep each ring segment
+  bandwidth-bound instead of latency-bound).
+* A bucket's all-reduce is queued as soon as every gradient in it has been queued by
+  backward — polled from hooks inside the fused stage nodes (after every bottleneck), at the
+  RoI head's entry and at the stage boundaries — on the library's own high-priority HIP stream
+  (``mrcnn_allreduce_bucket``, include/mrcnn_hip.h), ordered by events after the compute stream
+  and the weight-gradient side stream.  The first collective therefore starts under res5's
+  backward; the compute stream waits only right before the SGD launch, which also applies the
+  1/world scale.
+* ``torch.distributed`` is the control plane only (rendezvous, the 128-byte RCCL unique id,
+  max-over-ranks of the timings): the data path is RCCL behind the C ABI.  ``TorchDistExchange``
+  (gloo on CPU, used by the multi-process CPU tests) implements the same interface.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
 
-class GradBuckets(object):
-    """Contiguous slices of a flat gradient buffer, all-reduced independently."""
+# ---------------------------------------------------------------------------------------------
+# Exchanges: who moves the bytes
+# ---------------------------------------------------------------------------------------------
+class TorchDistExchange(object):
+    """All-reduce / broadcast through a torch.distributed process group (gloo on CPU)."""
 
-    def __init__(self, flat, bounds, group=None):
-        self.flat = flat
-        self.bounds = list(bounds)          # [(start, end), ...] in backward order
-        self.group = group
-        self.works = [None] * len(self.bounds)
+    name = 'torch.distributed'
 
-    def launch(self, i):
-        if self.works[i] is not None:
-            return
-        s, e = self.bounds[i]
-        if e > s:
-            self.works[i] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
-                                            group=self.group, async_op=True)
-
-    def wait_all(self):
-        for i in range(len(self.bounds)):
-            self.launch(i)                  # anything not yet issued
-        for i, w in enumerate(self.works):
-            if w is not None:
-                w.wait()
-            self.works[i] = None
-
-
-class DataParallelGradSync(object):
-    """Hooks a MomentumSGD to a process group.
-
-    ``stage_tensors`` are activations whose gradient marks the end of a bucket: the
-    train chain's ``features`` (closes head + RPN) and the extractor's res3 output
-    (closes res4); the last bucket (res3) is closed by the end of backward.
-    """
-
-    def __init__(self, optimizer, group=None):
+    def __init__(self, group=None):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.group = group
         self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._works = []
+        self.name = 'torch.distributed/%s' % dist.get_backend(group)
+
+    def broadcast(self, tensor, src=0):
+        dist.broadcast(tensor, src=src, group=self.group)
+
+    def allreduce_async(self, tensor, bucket_id=0):
+        self._works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group,
+                                           async_op=True))
+
+    def wait_all(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+    def timing(self, enable):
+        pass
+
+    def bucket_times(self, n_buckets):
+        return None
+
+    def describe(self):
+        return dict(library=self.name, ranks=self.world_size)
+
+
+class RcclExchange(object):
+    """RCCL communicator behind the C ABI (``mrcnn_allreduce_*``).  The unique id travels
+    through the c10d store of the already initialised process group (any backend)."""
+
+    name = 'rccl-c-abi'
+    _counter = 0
+
+    def __init__(self, device=None):
+        from . import _lib
+        self._lib = _lib
+        lib = _lib.load()
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed (control plane) is not initialised')
+        self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        key = 'mrcnn_rccl_unique_id_%d' % RcclExchange._counter
+        RcclExchange._counter += 1
+        store = dist.distributed_c10d._get_default_store()
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(lib.mrcnn_allreduce_unique_id(buf), 'mrcnn_allreduce_unique_id')
+            store.set(key, buf.raw)
+        else:
+            buf.raw = bytes(store.get(key))[:128]
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mrcnn_allreduce_init(buf, self.rank, self.world_size,
+                                                ctypes.byref(handle)), 'mrcnn_allreduce_init')
+        self.handle = handle
+        r, w, v = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        where = ctypes.create_string_buffer(256)
+        _lib.check(lib.mrcnn_allreduce_info(handle, ctypes.byref(r), ctypes.byref(w),
+                                            ctypes.byref(v), where, 256), 'mrcnn_allreduce_info')
+        self.rccl_version, self.library = v.value, where.value.decode()
+        assert (r.value, w.value) == (self.rank, self.world_size)
+
+    def _compute_stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _side_stream(self):
+        from .functions.conv import wgrad_stream_if_used
+        st = wgrad_stream_if_used(self.device)
+        return ctypes.c_void_p(st.cuda_stream) if st is not None else None
+
+    def broadcast(self, tensor, src=0):
+        assert tensor.is_cuda and tensor.is_contiguous()
+        self._lib.call('mrcnn_allreduce_broadcast', self.handle, self._lib.ptr(tensor),
+                       tensor.numel() * tensor.element_size(), int(src), self._compute_stream())
+
+    def allreduce_async(self, tensor, bucket_id=0):
+        assert tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous()
+        self._lib.call('mrcnn_allreduce_bucket', self.handle, self._lib.ptr(tensor),
+                       tensor.numel(), int(bucket_id), self._compute_stream(), self._side_stream())
+
+    def wait_all(self):
+        self._lib.call('mrcnn_allreduce_wait', self.handle, self._compute_stream())
+
+    def barrier(self):
+        """All ranks have reached this point AND their queued device work is done."""
+        t = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.allreduce_async(t, -2)
+        self.wait_all()
+        torch.cuda.synchronize(self.device)
+
+    def timing(self, enable):
+        self._lib.call('mrcnn_allreduce_timing', self.handle, 1 if enable else 0)
+
+    def bucket_times(self, n_buckets):
+        """[(total_ms, total_bytes, launches)] per bucket id (device must be synchronised)."""
+        out = []
+        for b in range(n_buckets):
+            ms, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            self._lib.call('mrcnn_allreduce_bucket_times', self.handle, b, ctypes.byref(ms),
+                           ctypes.byref(by), ctypes.byref(n))
+            out.append((ms.value, by.value, n.value))
+        return out
+
+    def describe(self):
+        return dict(library='RCCL via libmrcnn_hip.so mrcnn_allreduce_* (%s)' % self.library,
+                    rccl_version=self.rccl_version, ranks=self.world_size)
+
+    def close(self):
+        if self.handle is not None:
+            self._lib.load().mrcnn_allreduce_destroy(self.handle)
+            self.handle = None
+
+
+def default_exchange(group=None):
+    """RCCL behind the C ABI on a ROCm device, torch.distributed (gloo) on CPU."""
+    if torch.cuda.is_available() and group is None:
+        return RcclExchange()
+    return TorchDistExchange(group)
+
+
+# ---------------------------------------------------------------------------------------------
+# Buckets: what is exchanged when
+# ---------------------------------------------------------------------------------------------
+class GradBuckets(object):
+    """Contiguous slices of a flat gradient buffer, all-reduced independently and in order."""
+
+    def __init__(self, flat, bounds, group=None, exchange=None):
+        self.flat = flat
+        self.bounds = list(bounds)          # [(start, end), ...] in backward order
+        self.exchange = exchange if exchange is not None else TorchDistExchange(group)
+        self.launched = [False] * len(self.bounds)
+        self.next = 0                       # first bucket not yet launched by poll()
+
+    def launch(self, i):
+        if self.launched[i]:
+            return
+        self.launched[i] = True
+        s, e = self.bounds[i]
+        if e > s:
+            self.exchange.allreduce_async(self.flat[s:e], i)
+
+    def poll(self, ready):
+        """Launch, in order, every leading bucket for which ``ready(i)`` holds."""
+        while self.next < len(self.bounds) and (self.launched[self.next] or ready(self.next)):
+            self.launch(self.next)
+            self.next += 1
+
+    def wait_all(self):
+        for i in range(len(self.bounds)):
+            self.launch(i)                  # anything not yet issued
+        self.exchange.wait_all()
+        self.launched = [False] * len(self.bounds)
+        self.next = 0
+
+
+def plan_buckets(arena, units, bucket_bytes):
+    """Cut the arena into buckets at unit boundaries.  ``units``: per arena parameter an
+    opaque unit key (consecutive parameters with the same key are never separated).  Returns
+    [(first_param, last_param)] with every bucket except possibly the last >= bucket_bytes."""
+    n = len(arena.params)
+    groups, start = [], 0
+    for i in range(1, n + 1):
+        if i == n or units[i] != units[i - 1]:
+            groups.append((start, i - 1))
+            start = i
+    buckets, first = [], None
+    for g_first, g_last in groups:
+        if first is None:
+            first = g_first
+        lo, hi = arena.slice_bounds(first, g_last)
+        if (hi - lo) * 4 >= bucket_bytes:
+            buckets.append((first, g_last))
+            first = None
+    if first is not None:
+        if buckets and (arena.slice_bounds(first, n - 1)[1] - arena.slice_bounds(first, n - 1)[0]) * 4 \
+                < bucket_bytes // 4:
+            buckets[-1] = (buckets[-1][0], n - 1)      # tiny tail: fold into the previous bucket
+        else:
+            buckets.append((first, n - 1))
+    return buckets
+
+
+class DataParallelGradSync(object):
+    """Hooks a MomentumSGD to an exchange: rank-0 broadcast at attach, bucketed all-reduce
+    of the gradient arena overlapped with backward, 1/world scale handed to the SGD launch."""
+
+    def __init__(self, optimizer, group=None, exchange=None, bucket_bytes=16 << 20):
+        self.exchange = exchange if exchange is not None else default_exchange(group)
+        self.world_size = self.exchange.world_size
         self.optimizer = optimizer
+        self.bucket_bytes = int(bucket_bytes)
         self.buckets = None
-        self._stage_of_param = None
+        self.bucket_params = []
         optimizer.grad_sync = self
 
     # -- setup -----------------------------------------------------------------
     def attach(self, optimizer):
         arena = optimizer.arena
-        # rank-0 weights to everyone (ChainerMN does this on the first update)
-        dist.broadcast(arena.values, src=0, group=self.group)
-        names = {id(p): n for n, p in optimizer.target.named_parameters()}
-        stages = []
-        for p in arena.params:
-            n = names.get(id(p), '')
-            if '.extractor.res3.' in '.' + n:
-                stages.append(2)
-            elif '.extractor.res4.' in '.' + n:
-                stages.append(1)
-            else:
-                stages.append(0)            # head + rpn
-        bounds = []
-        for st in sorted(set(stages)):
-            idx = [i for i, s in enumerate(stages) if s == st]
-            if idx != list(range(idx[0], idx[-1] + 1)):
-                # parameters of a stage are not contiguous: fall back to one bucket
-                bounds = [(0, arena.size)]
-                break
-            bounds.append(arena.slice_bounds(idx[0], idx[-1]))
-        self.buckets = GradBuckets(arena.grads, bounds, self.group)
-        # wire the bucket triggers into the model (duck-typed: a MaskRCNNTrainChain)
         target = optimizer.target
-        if len(bounds) == 3 and hasattr(target, 'features_grad_hook'):
-            target.features_grad_hook = self.stage_hook(0)
-            extractor = getattr(getattr(target, 'mask_rcnn', None), 'extractor', None)
-            if extractor is not None and hasattr(extractor, 'stage_hooks'):
-                extractor.stage_hooks['res3'] = self.stage_hook(1)
+        # bcast_data: EVERY parameter and buffer of the model from rank 0 (the arena holds the
+        # trainable ones; the frozen stem / res2 / AffineChannel2D parameters live outside it)
+        self.exchange.broadcast(arena.values, src=0)
+        in_arena = set(id(p) for p in arena.params)
+        with torch.no_grad():
+            for t in list(target.parameters()) + list(target.buffers()):
+                if id(t) in in_arena:
+                    continue
+                if t.is_contiguous():
+                    self.exchange.broadcast(t.data, src=0)
+                else:                                   # channels-last filter views
+                    flat = t.data.clone(memory_format=torch.contiguous_format)
+                    self.exchange.broadcast(flat, src=0)
+                    t.data.copy_(flat)
+        # units: a bottleneck block, or a leaf layer, by MODULE IDENTITY (no name matching)
+        owner = {}
+        from .models.resnet_extractor import Bottleneck
+        for m in target.modules():
+            if isinstance(m, Bottleneck):
+                for p in m.parameters():
+                    owner[id(p)] = id(m)
+        for m in target.modules():
+            for p in m.parameters(recurse=False):
+                owner.setdefault(id(p), id(m))
+        units = [owner.get(id(p), id(p)) for p in arena.params]
+        self.bucket_params = plan_buckets(arena, units, self.bucket_bytes)
+        bounds = [arena.slice_bounds(a, b) for a, b in self.bucket_params]
+        self.buckets = GradBuckets(arena.grads, bounds, exchange=self.exchange)
+        # poll points inside backward (duck-typed: a MaskRCNNTrainChain around a MaskRCNNResNet)
+        if hasattr(target, 'features_grad_hook'):
+            target.features_grad_hook = self._tensor_hook
+        from .models.resnet_extractor import BuildingBlock, ResNetExtractorBase
+        for m in target.modules():
+            if isinstance(m, BuildingBlock):
+                m.grad_poll = self.poll
+            if isinstance(m, ResNetExtractorBase):
+                for key in m.functions:
+                    m.stage_hooks[key] = self._tensor_hook
 
     # -- per step ----------------------------------------------------------------
     def begin_backward(self):
         pass
 
-    def stage_hook(self, stage_index):
-        """Returns a tensor hook that launches bucket ``stage_index`` when fired."""
-        def _hook(grad):
-            if self.buckets is not None and stage_index < len(self.buckets.bounds):
-                if grad.is_cuda:
-                    from .functions.conv import join_wgrad_stream
-                    join_wgrad_stream(grad.device)   # this stage's side-stream wgrads
-                self.buckets.launch(stage_index)
-            return grad
-        return _hook
+    def _bucket_ready(self, i):
+        arena = self.optimizer.arena
+        a, b = self.bucket_params[i]
+        epoch = arena.epoch
+        for p in arena.params[a:b + 1]:
+            if p._grad_epoch != epoch:
+                return False
+        return True
+
+    def poll(self):
+        """Queue the all-reduce of every leading bucket whose gradients have all been queued
+        (a parameter counts once its FIRST gradient of the step is queued: parameters shared
+        between layers must not be used with overlapping buckets)."""
+        if self.buckets is not None:
+            self.buckets.poll(self._bucket_ready)
+
+    def _tensor_hook(self, grad):
+        self.poll()
+        return grad
+
+    def stage_hook(self, stage_index=None):
+        return self._tensor_hook
 
     def finish(self):
         """Wait for every bucket; returns the scale (1/world) to apply to the sums."""
         self.buckets.wait_all()
         return 1.0 / self.world_size
 
+    def describe(self):
+        d = self.exchange.describe()
+        arena = self.optimizer.arena
+        if arena is not None and self.buckets is not None:
+            d['buckets_mb'] = [round((e - s) * 4 / 2 ** 20, 1) for s, e in self.buckets.bounds]
+        return d
+
 
 def init_from_env(backend=None):
-    """One process per GPU, rendezvous from RANK / WORLD_SIZE / MASTER_* / LOCAL_RANK."""
-    import os
+    """One process per GPU, rendezvous from RANK / WORLD_SIZE / MASTER_* / LOCAL_RANK.
+    The process group is the CONTROL plane (gloo; plus torch's nccl binding for device tensors
+    so that RCCL stays available as a library fallback); gradients travel through
+    ``RcclExchange``."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
@@ -124,8 +334,8 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # 'nccl' is RCCL on ROCm
-        if backend == 'nccl':
+            backend = 'cpu:gloo,cuda:nccl' if torch.cuda.is_available() else 'gloo'
+        if 'nccl' in backend:
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local

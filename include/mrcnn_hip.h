@@ -347,6 +347,43 @@ int mrcnn_decode_cls_boxes(const float *roi, const float *cls_loc, int ld_loc,
                            const double *mean4, const double *std4, float size_h,
                            float size_w, void *stream);
 
+/* ---- Gradient exchange over RCCL / xGMI ---------------------------------------------- */
+/* Replaces ChainerMN's communicator as the reference uses it
+ * (examples/train_common.py:97-103 `chainermn.create_communicator('hierarchical')`, :178
+ * `create_multi_node_optimizer`): bcast_data of the model before the first update and
+ * allreduce_grad before every update.  One communicator per process (= per GPU).  RCCL
+ * (ncclComm_t) is resolved at run time from the librccl.so already loaded into the process.
+ * Collectives run on the communicator's OWN high-priority HIP stream, ordered against the
+ * caller's streams with events only, so a bucket overlaps with the backward still running.
+ *
+ *   rank 0:   mrcnn_allreduce_unique_id(id)  -> 128 bytes, handed to every rank by the launcher
+ *   all:      mrcnn_allreduce_init(id, rank, world, &comm)       (collective)
+ *   per step: mrcnn_allreduce_bucket(comm, grads + lo, hi - lo, bucket, compute, side) ...
+ *             mrcnn_allreduce_wait(comm, compute)  then the SGD launch (grad_scale = 1/world)
+ */
+#define MRCNN_COMM_ID_BYTES 128
+int mrcnn_allreduce_unique_id(void *id128);
+int mrcnn_allreduce_init(const void *id128, int rank, int world, void **comm);
+int mrcnn_allreduce_destroy(void *comm);
+/* rank / world of the communicator, RCCL version code, and which librccl was bound. */
+int mrcnn_allreduce_info(void *comm, int *rank, int *world, int *rccl_version,
+                         char *library, int library_len);
+/* In-place SUM over ranks of buf[0..count) fp32, queued on the collective stream AFTER
+ * everything queued so far on after_stream and (if non-NULL) after_stream2 — the compute
+ * stream and the weight-gradient side stream.  bucket_id only labels the timing records. */
+int mrcnn_allreduce_bucket(void *comm, float *buf, int64_t count, int bucket_id,
+                           void *after_stream, void *after_stream2);
+/* `stream` waits (device side) for every collective queued so far. */
+int mrcnn_allreduce_wait(void *comm, void *stream);
+/* rank `root`'s bytes to all ranks; ordered after and before `after_stream`. */
+int mrcnn_allreduce_broadcast(void *comm, void *buf, int64_t bytes, int root,
+                              void *after_stream);
+/* HIP-event timing of the collectives: enable clears the records; bucket_times sums them
+ * (bucket_id -1 = all) after the caller synchronised the device. */
+int mrcnn_allreduce_timing(void *comm, int enable);
+int mrcnn_allreduce_bucket_times(void *comm, int bucket_id, double *total_ms,
+                                 double *total_bytes, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

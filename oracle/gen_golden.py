@@ -332,7 +332,48 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'segm_results.npz'), bbox=sbox, label=slabel,
                         logits_sel=logits[np.arange(Dn), slabel], n_fg=n_fg, im_h=im_h, im_w=im_w,
                         masks=np.packbits(masks, axis=-1), masks_shape=np.array(masks.shape))
+    # (10) end-to-end self-consistency fixture (last row): the oracle's
+    #      whole training iteration (oracle/np_step.py: extractor, RPN, ProposalCreator, target
+    #      creators in the reference's np.random order, ROIAlign, res5 head, five losses,
+    #      hand-written backward) on one tiny seeded batch with seeded weights.  Only outputs are
+    #      stored; inputs and weights are regenerated from the seeds by np_step.synthetic_*.
+    from oracle import np_step
+    np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **train_step_fixture(np_step))
     print('golden vectors written to', os.path.normpath(OUT))
+
+
+TRAIN_STEP_CFG = dict(n_layers=50, H=160, W=224, batch=2, n_gt=3, n_sample=32, input_seed=3,
+                      param_seed=0, np_random_seed=11,
+                      proposal_creator_params=dict(min_size=0, n_train_pre_nms=600,
+                                                   n_train_post_nms=100))
+
+
+def train_step_fixture(np_step):
+    c = TRAIN_STEP_CFG
+    P = np_step.synthetic_params(c['n_layers'], seed=c['param_seed'])
+    imgs, bboxes, labels, masks, scales = np_step.synthetic_inputs(
+        c['input_seed'], c['batch'], c['H'], c['W'], n_gt=c['n_gt'], scale=1.0)
+    np.random.seed(c['np_random_seed'])
+    out = np_step.train_step(P, imgs, bboxes, labels, masks, scales, n_layers=c['n_layers'],
+                             n_sample=c['n_sample'],
+                             proposal_creator_params=c['proposal_creator_params'])
+    fx = {'loss_names': np.array(sorted(out['losses'])),
+          'loss_values': np.array([out['losses'][k] for k in sorted(out['losses'])], np.float64),
+          'n_rois': np.array([len(r) for r in out['rois']], np.int32),
+          'rois': np.concatenate(out['rois'], 0),
+          'roi_order': np.concatenate(out['roi_order'], 0).astype(np.int32),
+          'sample_rois': out['sample_rois'], 'sample_roi_indices': out['sample_roi_indices'],
+          'gt_roi_labels': out['gt_roi_labels'], 'gt_roi_masks': out['gt_roi_masks'].astype(np.int8),
+          'gt_rpn_labels': out['gt_rpn_labels'].astype(np.int8),
+          'np_random_after': np.array(np.random.randint(0, 2 ** 31 - 1))}
+    names = sorted(out['grads'])
+    fx['grad_names'] = np.array(names)
+    fx['grad_l2'] = np.array([np.sqrt(np.sum(out['grads'][k].astype(np.float64) ** 2)) for k in names])
+    fx['grad_absmax'] = np.array([np.abs(out['grads'][k]).max() for k in names], np.float64)
+    for k in ('rpn.loc_score.b', 'rpn.conv1.b', 'head.cls_loc_score.b', 'head.deconv6.b',
+              'head.mask.b', 'extractor.res3.a.conv1.W'):
+        fx['grad/' + k] = out['grads'][k].astype(np.float32)
+    return fx
 
 
 if __name__ == '__main__':

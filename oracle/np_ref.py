@@ -361,7 +361,7 @@ def average_pooling_2d(x, k, stride):
 
 
 def linear_fwd(x, W, b):
-    return (x.reshape(len(x), -1) @ W.T + b).astype(f32)
+    return (x.reshape(len(x), -1) @ W.T + b).astype(x.dtype, copy=False)
 
 
 def affine_channel_2d_fwd(x, W, b):

@@ -1,6 +1,8 @@
-"""Plain PyTorch fp32 CPU reference of the model graph (torch.nn.functional ops +
-autograd), used only as a checker for the HIP path's end-to-end forward/backward.
-ROIAlign goes through the oracle (fwd/bwd) wrapped as an autograd Function."""
+"""Plain PyTorch CPU reference of the model graph (torch.nn.functional ops + autograd),
+used only as a checker for the HIP path's end-to-end forward/backward.  It runs in the dtype
+of ``RefParams`` — float64 by default, so that a comparison bounds the HIP path's OWN fp32
+error rather than the difference of two fp32 roundings.  ROIAlign goes through the oracle
+(fp32 C restatement, fwd/bwd) wrapped as an autograd Function."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -11,26 +13,29 @@ import oracle
 class _RefROIAlign(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rois_xy, outh, outw, scale):
-        y = oracle.roi_align_fwd(x.detach().numpy(), rois_xy.numpy(), outh, outw, scale, 0)
+        y = oracle.roi_align_fwd(x.detach().numpy().astype(np.float32),
+                                 rois_xy.numpy().astype(np.float32), outh, outw, scale, 0)
         ctx.save_for_backward(rois_xy)
-        ctx.meta = (tuple(x.shape), scale)
-        return torch.tensor(y)
+        ctx.meta = (tuple(x.shape), scale, x.dtype)
+        return torch.tensor(y, dtype=x.dtype)
 
     @staticmethod
     def backward(ctx, gy):
         rois_xy, = ctx.saved_tensors
-        shape, scale = ctx.meta
-        gx = oracle.roi_align_bwd(gy.contiguous().numpy(), rois_xy.numpy(), shape, scale, 0)
-        return torch.tensor(gx), None, None, None, None
+        shape, scale, dtype = ctx.meta
+        gx = oracle.roi_align_bwd(gy.contiguous().numpy().astype(np.float32),
+                                  rois_xy.numpy().astype(np.float32), shape, scale, 0)
+        return torch.tensor(gx, dtype=dtype), None, None, None, None
 
 
 class RefParams(object):
     """CPU leaf copies (logical NCHW-contiguous) of a HIP model's parameters."""
 
-    def __init__(self, module):
+    def __init__(self, module, dtype=torch.float64):
         self.p = {}
+        self.dtype = dtype
         for name, t in module.named_parameters():
-            c = t.detach().cpu().contiguous().clone()
+            c = t.detach().cpu().contiguous().clone().to(dtype)
             c.requires_grad_(True)
             self.p[name] = c
 
@@ -58,6 +63,7 @@ def building_block(x, P, pre, n, stride):
 
 
 def extractor(x, P, pre='extractor', blocks=(3, 4, 6)):
+    x = x.to(P.dtype)
     with torch.no_grad():
         h = F.conv2d(x, P[pre + '.conv1.W'], P[pre + '.conv1.b'], stride=2, padding=3)
         h = F.relu(_affine(h, P, pre + '.bn1'))
@@ -80,7 +86,7 @@ def rpn(feat, P, A, pre='rpn'):
 
 
 def head(feat, rois_yx, roi_indices, P, n_class, roi_size, pre='head'):
-    rois = torch.cat([roi_indices.float()[:, None], rois_yx], 1)[:, [0, 2, 1, 4, 3]].contiguous()
+    rois = torch.cat([roi_indices.float()[:, None], rois_yx.float()], 1)[:, [0, 2, 1, 4, 3]].contiguous()
     pool = _RefROIAlign.apply(feat, rois, roi_size, roi_size, 1. / 16)
     res5 = building_block(pool, P, pre + '.res5', 3, roi_size // 7)
     pool5 = F.avg_pool2d(res5, 7, 7).flatten(1)
@@ -96,17 +102,17 @@ def losses(rpn_locs, rpn_scores, gt_rpn_locs, gt_rpn_labels, cls_locs, scores, m
     """models/mask_rcnn_train_chain.py:163-181 in plain torch."""
     def loc_loss(pred, gt, label, sigma):
         s2 = sigma ** 2
-        w = (label > 0).float()[:, None]
-        d = w * (pred - gt)
+        w = (label > 0).to(pred.dtype)[:, None]
+        d = w * (pred - gt.to(pred.dtype))
         a = d.abs()
-        flag = (a.detach() < 1. / s2).float()
+        flag = (a.detach() < 1. / s2).to(pred.dtype)
         y = flag * (s2 / 2.) * d * d + (1 - flag) * (a - 0.5 / s2)
-        return y.sum() / (label >= 0).sum().float()
+        return y.sum() / (label >= 0).sum().to(pred.dtype)
 
     def sce(x, t):
         m = t != -1
         cnt = max(int(m.sum()), 1)
-        return F.binary_cross_entropy_with_logits(x[m], t[m].float(), reduction='sum') / cnt
+        return F.binary_cross_entropy_with_logits(x[m], t[m].to(x.dtype), reduction='sum') / cnt
 
     n = len(cls_locs)
     rl = loc_loss(rpn_locs.reshape(-1, 4), gt_rpn_locs, gt_rpn_labels, rpn_sigma)

@@ -1,6 +1,9 @@
 """fp32-MFMA implicit-GEMM convolution family vs the NumPy oracle (np_ref) on the
-same seeded inputs.  Tolerance: north_star's 1e-4 relative for fp32 conv (applied
-against the tensor's scale: GEMM summation order differs from BLAS')."""
+same seeded inputs.  Tolerance: north_star's 1e-4 relative for fp32 conv, PER ELEMENT:
+|got - ref| <= 1e-4 * |ref| + 1e-5 * max|ref| (the absolute floor covers elements that cancel
+to ~0, where no fp32 summation order has a bounded relative error).  Where it is cheap the
+oracle is evaluated in float64 on the same fp32 inputs, so the bound is on the HIP result's
+own error, not on the difference of two fp32 roundings."""
 import numpy as np
 import pytest
 import torch
@@ -11,10 +14,20 @@ from chainer_mask_rcnn_amd import functions as F
 pytestmark = pytest.mark.gpu
 
 
-def _close(got, ref, rel=1e-4):
+def _close(got, ref, rel=1e-4, floor=1e-5):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape
     scale = max(np.abs(ref).max(), 1e-6)
-    err = np.abs(got - ref).max()
-    assert err <= rel * scale, 'max err %.3e vs scale %.3e' % (err, scale)
+    excess = np.abs(got - ref) - (rel * np.abs(ref) + floor * scale)
+    worst = excess.max()
+    assert worst <= 0, 'element %s: got %.9g ref %.9g (scale %.3e)' % (
+        np.unravel_index(excess.argmax(), excess.shape), got.flat[excess.argmax()],
+        ref.flat[excess.argmax()], scale)
+
+
+def _64(*arrays):
+    return [None if a is None else np.asarray(a, np.float64) for a in arrays]
 
 
 def _t(a, dev, grad=False):
@@ -52,11 +65,11 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     b = rng.standard_normal(K).astype(np.float32)
     xt, wt, bt = _t(x, dev, True), _t(Wt, dev, True), _t(b, dev, True)
     y = F.conv2d(xt, wt, bt, stride=s, pad=p)
-    y_ref = np_ref.conv2d_fwd(x, Wt, b, s, p)
+    y_ref = np_ref.conv2d_fwd(*_64(x, Wt, b), s, p)
     _close(y.detach().cpu().numpy(), y_ref)
     gy = rng.standard_normal(y_ref.shape).astype(np.float32)
     y.backward(_t(gy, dev))
-    gx, gW, gb = np_ref.conv2d_bwd(x, Wt, gy, s, p)
+    gx, gW, gb = np_ref.conv2d_bwd(*_64(x, Wt, gy), s, p)
     _close(xt.grad.cpu().numpy(), gx)
     _close(wt.grad.cpu().numpy(), gW)
     _close(bt.grad.cpu().numpy(), gb)
@@ -113,12 +126,13 @@ def test_linear(dev):
     b = rng.standard_normal(Cout).astype(np.float32)
     xt, wt, bt = _t(x, dev, True), _t(Wt, dev, True), _t(b, dev, True)
     y = F.linear(xt, wt, bt)
-    _close(y.detach().cpu().numpy(), np_ref.linear_fwd(x, Wt, b))
+    _close(y.detach().cpu().numpy(), np_ref.linear_fwd(*_64(x, Wt, b)))
     gy = rng.standard_normal((R, Cout)).astype(np.float32)
     y.backward(_t(gy, dev))
-    _close(xt.grad.cpu().numpy(), gy @ Wt)
-    _close(wt.grad.cpu().numpy(), gy.T @ x)
-    _close(bt.grad.cpu().numpy(), gy.sum(0))
+    x6, W6, g6 = _64(x, Wt, gy)
+    _close(xt.grad.cpu().numpy(), g6 @ W6)
+    _close(wt.grad.cpu().numpy(), g6.T @ x6)
+    _close(bt.grad.cpu().numpy(), g6.sum(0))
 
 
 def test_stem_conv(dev):
@@ -363,7 +377,7 @@ def test_position_major_wgrad(dev, case):
             outs.append(w.grad.clone())
     finally:
         lib.mrcnn_set_tuning(b'position_major_rows', 1)
-    _, gW, _ = np_ref.conv2d_bwd(x, np.zeros((K, C, 3, 3), np.float32), gy, 1, 1)
+    _, gW, _ = np_ref.conv2d_bwd(*_64(x, np.zeros((K, C, 3, 3), np.float32), gy), 1, 1, need_gx=False)
     _close(outs[0].cpu().numpy(), gW)
     _close(outs[1].cpu().numpy(), gW)
     assert not torch.equal(outs[0], outs[1]) or True     # orders differ; values agree to 1e-4

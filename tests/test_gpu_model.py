@@ -1,6 +1,7 @@
 """End-to-end: the assembled HIP model (extractor, RPN, head, losses, backward, SGD) vs a
-plain PyTorch fp32 CPU reference of the same graph with the same weights and the same
-targets, on a tiny image.  Integer outputs (proposals) are compared with the oracle."""
+plain PyTorch float64 CPU reference of the same graph with the same weights and the same
+targets, on a tiny image — for ResNet-50 (BASELINE configs[1]) and ResNet-101 (configs[3]).
+Integer outputs (proposals) are compared with the oracle."""
 import numpy as np
 import pytest
 import torch
@@ -20,16 +21,19 @@ def _rel(got, ref):
     return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
 
 
-@pytest.fixture(scope='module')
-def setup(dev):
-    return _build(dev)
+@pytest.fixture(scope='module', params=[50, 101])
+def setup(dev, request):
+    return _build(dev, request.param)
 
 
-def _build(dev):
+_BLOCKS = {50: (3, 4, 6), 101: (3, 4, 23)}      # models/resnet_extractor.py:93-124
+
+
+def _build(dev, n_layers=50):
     torch.manual_seed(0)
     np.random.seed(0)
     model = cmr.models.MaskRCNNResNet(
-        50, n_fg_class=80, anchor_scales=(2, 4, 8, 16, 32), roi_size=14, min_size=H, max_size=W,
+        n_layers, n_fg_class=80, anchor_scales=(2, 4, 8, 16, 32), roi_size=14, min_size=H, max_size=W,
         proposal_creator_params=dict(min_size=0, n_train_pre_nms=600, n_train_post_nms=100,
                                      n_test_pre_nms=300, n_test_post_nms=50))
     # make the affine layers non-trivial
@@ -38,6 +42,12 @@ def _build(dev):
             if isinstance(m, cmr.links.AffineChannel2D):
                 m.W.uniform_(0.4, 0.9)
                 m.b.normal_(0, 0.1)
+        if n_layers == 101:
+            # 23 residual blocks with random filters: damp each block's residual branch so the
+            # activations stay O(1) through res4 (trained BN-derived affines do this)
+            for name, m in model.extractor.res4.named_modules():
+                if name.endswith('bn3'):
+                    m.W.mul_(0.5)
         model.rpn.conv1.b.normal_(0, 0.1)
         model.head.deconv6.b.normal_(0, 0.1)
     chain = cmr.models.MaskRCNNTrainChain(
@@ -57,13 +67,24 @@ def _build(dev):
     return model, chain, imgs, bboxes, labels, masks
 
 
+def freeze_like_reference(model, chain):
+    """examples/train_common.py:185-190: conv1, bn1, res2 and every AffineChannel2D."""
+    optimizers.disable_update(model.extractor.conv1)
+    optimizers.disable_update(model.extractor.bn1)
+    optimizers.disable_update(model.extractor.res2)
+    for m in chain.modules():
+        if isinstance(m, cmr.links.AffineChannel2D):
+            optimizers.disable_update(m)
+
+
 def test_extractor_and_rpn_forward(dev, setup):
     model, chain, imgs, *_ = setup
+    blocks = _BLOCKS[len(model.extractor.res4._names) == 23 and 101 or 50]
     P = ref_model.RefParams(model)
     x = torch.tensor(imgs)
     with torch.no_grad():
         feat = model.extractor(torch.tensor(imgs, device=dev))
-        feat_ref = ref_model.extractor(x, P)
+        feat_ref = ref_model.extractor(x, P, blocks=blocks)
         assert tuple(feat.shape) == tuple(feat_ref.shape) == (2, 1024, 11, 15)
         assert _rel(feat, feat_ref) < 1e-4
         model.eval()
@@ -90,8 +111,9 @@ def test_train_step_matches_reference(dev, setup):
     rep = {k: float(v) for k, v in chain.report.items()}
 
     # CPU reference with the same sampled RoIs / targets (replay the RNG stream)
+    blocks = _BLOCKS[len(model.extractor.res4._names) == 23 and 101 or 50]
     P = ref_model.RefParams(model)
-    feat = ref_model.extractor(torch.tensor(imgs), P)
+    feat = ref_model.extractor(torch.tensor(imgs), P, blocks=blocks)
     rl, rs = ref_model.rpn(feat, P, 15)
     with torch.no_grad():
         locs, scores, rois, roi_indices, anchor = model.rpn(
@@ -119,8 +141,16 @@ def test_train_step_matches_reference(dev, setup):
         assert abs(rep[n] - v.item()) <= 1e-4 * max(abs(v.item()), 1e-3), (n, rep[n], v.item())
     assert abs(rep['loss'] - ref_loss.item()) <= 1e-4 * abs(ref_loss.item())
 
-    # gradients of every trainable parameter
-    worst = 0.
+    # gradients of every trainable parameter, against the float64 graph: north_star's 1e-4
+    # relative for fp32 conv, measured against the gradient tensor's scale.
+    # A ReLU whose pre-activation lies within fp32 rounding of zero is decided differently by
+    # ANY two fp32 summation orders (and by the float64 graph): one such flip moves one row of
+    # the adjacent weight gradients by the contribution of one pixel, ~1e-4..1e-3 of the
+    # tensor's scale.  tools/grad_floor.py measures this floor with torch's CPU fp32 kernels on
+    # the same graph: worst layer 5.8e-4 (R-50) / 3.1e-4 (R-101) for CPU-fp32, 6.1e-5 / 5.6e-4
+    # for the HIP path (different layers flip in each).  Hence: every tensor has >= 99.9 % of
+    # its entries within 1e-4, and no entry is off by more than 2e-3.
+    worst, worst_name, worst_frac = 0., None, 0.
     for name, p in model.named_parameters():
         g_ref = P['' + name].grad
         if name.startswith('extractor.conv1') or name.startswith('extractor.bn1') \
@@ -128,10 +158,16 @@ def test_train_step_matches_reference(dev, setup):
             continue
         assert p.grad is not None, name
         assert g_ref is not None, name
-        r = _rel(p.grad, g_ref)
-        worst = max(worst, r)
-        assert r < 2e-3, (name, r)
-    print('worst relative gradient error', worst)
+        got, ref = p.grad.detach().cpu().double(), g_ref.detach().double()
+        err = (got - ref).abs() / ref.abs().max().clamp_min(1e-12)
+        frac = float((err > 1e-4).double().mean())
+        worst_frac = max(worst_frac, frac)
+        assert frac <= 1e-3, (name, frac)
+        if float(err.max()) > worst:
+            worst, worst_name = float(err.max()), name
+    print('worst relative gradient error %.3e (%s), largest fraction of entries beyond 1e-4: %.2e'
+          % (worst, worst_name, worst_frac))
+    assert worst < 2e-3, (worst_name, worst)
 
 
 def test_optimizer_arena_step(dev, setup):
@@ -141,17 +177,14 @@ def test_optimizer_arena_step(dev, setup):
     opt = optimizers.MomentumSGD(lr=0.01, momentum=0.9)
     opt.setup(chain)
     opt.add_hook(optimizers.WeightDecay(1e-4))
-    optimizers.disable_update(model.extractor.conv1)
-    optimizers.disable_update(model.extractor.bn1)
-    optimizers.disable_update(model.extractor.res2)
-    for m in chain.modules():
-        if isinstance(m, cmr.links.AffineChannel2D):
-            optimizers.disable_update(m)
+    freeze_like_reference(model, chain)
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
     np.random.seed(5)
     opt.update(chain, torch.tensor(imgs, device=dev), bboxes, labels, masks, [1., 1.])
     opt.update(chain, torch.tensor(imgs, device=dev), bboxes, labels, masks, [1., 1.])
     torch.cuda.synchronize()
+    # update() cleared the gradient arena in the SGD launch (cleargrads of the next iteration)
+    assert float(opt.arena.grads.abs().max()) == 0.
     n_train = 0
     for n, p in model.named_parameters():
         if not p.requires_grad:
@@ -160,10 +193,20 @@ def test_optimizer_arena_step(dev, setup):
             n_train += p.numel()
             assert not torch.equal(p, before[n]), n
             assert torch.isfinite(p).all()
-    # R-50 trainable parameter count (35.70 M without affine) + fused-head padding
-    assert 35.6e6 < n_train < 35.8e6
-    # second step equals the oracle rule applied to the arena
+    # trainable parameter count (35.70 M R-50 / 54.64 M R-101 without affine)
+    # + fused-head padding
+    if len(model.extractor.res4._names) == 23:
+        assert 54.5e6 < n_train < 54.8e6
+    else:
+        assert 35.6e6 < n_train < 35.8e6
+    # a third step equals the oracle rule applied to the arena (gradients from a plain
+    # forward/backward; step() without zeroing keeps them readable)
     a = opt.arena
+    loss = chain(torch.tensor(imgs, device=dev), bboxes, labels, masks, [1., 1.])
+    loss.backward()
+    from chainer_mask_rcnn_amd.functions.conv import join_wgrad_stream
+    join_wgrad_stream()
+    assert all(a.written()), 'every arena parameter received a gradient'
     p0, v0 = a.values.clone(), a.momenta.clone()
     g = a.grads.clone()
     opt.step()
@@ -214,6 +257,7 @@ def test_training_is_bit_reproducible_run_to_run(dev):
         opt = optimizers.MomentumSGD(lr=0.002, momentum=0.9)
         opt.setup(chain)
         opt.add_hook(optimizers.WeightDecay(1e-4))
+        freeze_like_reference(model, chain)
         x = torch.tensor(imgs, device=dev)
         np.random.seed(5)
         losses = []
@@ -226,3 +270,72 @@ def test_training_is_bit_reproducible_run_to_run(dev):
     l2, w2 = run()
     assert all(np.isfinite(l1)) and l1 == l2
     assert torch.equal(w1, w2)
+
+
+def test_optimizer_ownership_rules(dev):
+    """chainer semantics of the flat arena (optimizers.py): an un-disabled AffineChannel2D
+    raises; layers below freeze_at are never updated even if left enabled; a parameter without
+    a gradient in a step is skipped entirely; a dropped .grad is re-bound; two backward passes
+    before one step accumulate."""
+    from chainer_mask_rcnn_amd.functions.conv import join_wgrad_stream
+    model, chain, imgs, bboxes, labels, masks = _build(dev)
+    opt = optimizers.MomentumSGD(lr=1e-4, momentum=0.9)
+    opt.setup(chain)
+    opt.add_hook(optimizers.WeightDecay(1e-4))
+    x = torch.tensor(imgs, device=dev)
+    with pytest.raises(ValueError, match='AffineChannel2D'):
+        opt.update(chain, x, bboxes, labels, masks, [1., 1.])
+    for m in chain.modules():
+        if isinstance(m, cmr.links.AffineChannel2D):
+            optimizers.disable_update(m)
+    # conv1 / res2 deliberately left enabled: unchain_backward -> grad None -> never updated
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    np.random.seed(5)
+    opt.update(chain, x, bboxes, labels, masks, [1., 1.])
+    for n, p in model.named_parameters():
+        if n.startswith('extractor.conv1') or n.startswith('extractor.res2'):
+            assert torch.equal(p, before[n]), n
+    arena = opt.arena
+    assert all(p is not model.extractor.conv1.W for p in arena.params)
+
+    # (1) no gradient in a step -> the parameter is skipped (no weight decay, no momentum decay):
+    # run the head without its mask branch
+    w_mask = model.head.mask.W
+    i_mask = [i for i, p in enumerate(arena.params) if p is w_mask][0]
+    lo, hi = arena.slice_bounds(i_mask, i_mask)
+    snap_p, snap_v = arena.values[lo:hi].clone(), arena.momenta[lo:hi].clone()
+    assert float(snap_v.abs().max()) > 0
+    feat = model.extractor(x)
+    t = chain.last_targets
+    idx = torch.zeros(len(t['sample_rois']), dtype=torch.int32, device=dev)
+    cls_locs, scores, _ = model.head(feat, t['sample_rois'], idx, pred_mask=False)
+    (cls_locs.sum() * 1e-4 + scores.sum() * 1e-4).backward()
+    join_wgrad_stream()
+    written = dict(zip([id(p) for p in arena.params], arena.written()))
+    assert not written[id(w_mask)] and not written[id(model.head.deconv6.W)]
+    assert written[id(model.head.cls_loc_score.W)] and written[id(model.extractor.res3.a.conv1.W)]
+    opt.step(zero_grads=True)
+    assert torch.equal(arena.values[lo:hi], snap_p) and torch.equal(arena.momenta[lo:hi], snap_v)
+    assert float(arena.grads.abs().max()) == 0.
+
+    # (2) zero_grad(set_to_none=True) drops the arena views: autograd allocates fresh tensors,
+    # rebind() (called by step()) folds them in and restores the views
+    chain.zero_grad(set_to_none=True)
+    np.random.seed(6)
+    chain(x, bboxes, labels, masks, [1., 1.]).backward()
+    join_wgrad_stream()
+    g_foreign = model.head.mask.W.grad.clone()
+    assert not arena.aliases(i_mask)
+    arena.rebind()
+    assert arena.aliases(i_mask) and torch.equal(model.head.mask.W.grad, g_foreign)
+    g_once = arena.grads.clone()
+    assert torch.isfinite(g_once).all()
+
+    # (3) a second backward before the step accumulates (the first gradient of a step is written
+    # in place, later ones go through autograd's accumulation into the same arena view)
+    np.random.seed(6)
+    chain(x, bboxes, labels, masks, [1., 1.]).backward()
+    join_wgrad_stream()
+    torch.cuda.synchronize()
+    scale = float(g_once.abs().max())
+    assert float((arena.grads - 2 * g_once).abs().max()) <= 1e-5 * scale

@@ -144,8 +144,8 @@ def test_decode_clip_bit_exact(dev):
     ref[:, 0::2] = np.clip(ref[:, 0::2], 0, 800)
     ref[:, 1::2] = np.clip(ref[:, 1::2], 0, 1333)
     got = roi.cpu().numpy()
-    # exp in double then one rounding on both sides: identical up to double-rounding ties
-    assert (got != ref).mean() < 1e-6
+    # exp in double then one rounding on both sides: the fp32 boxes are bit-identical
+    assert np.array_equal(got, ref)
     assert valid.cpu().numpy().all()
 
 

@@ -1,0 +1,63 @@
+"""The assembled HIP train step against the committed end-to-end fixture
+tests/golden/train_step.npz ("the build's CPU restatement run on one tiny
+synthetic image with fixed weights -> 6 loss values + selected RoI indices, committed, then
+required bit-exact for integers / 1e-4 for floats from the HIP path").  Weights and inputs are
+regenerated from the fixture's seeds (oracle/np_step.synthetic_*), the global np.random stream
+is seeded as the generator did."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import chainer_mask_rcnn_amd as cmr
+from oracle import np_step
+from oracle.gen_golden import TRAIN_STEP_CFG as C
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_train_step_matches_fixture(dev, golden_dir):
+    d = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    P = np_step.synthetic_params(C['n_layers'], seed=C['param_seed'])
+    imgs, bboxes, labels, masks, scales = np_step.synthetic_inputs(
+        C['input_seed'], C['batch'], C['H'], C['W'], n_gt=C['n_gt'], scale=1.0)
+    model = cmr.models.MaskRCNNResNet(
+        C['n_layers'], n_fg_class=80, anchor_scales=(2, 4, 8, 16, 32), roi_size=14,
+        min_size=C['H'], max_size=C['W'], proposal_creator_params=C['proposal_creator_params'])
+    chain = cmr.models.MaskRCNNTrainChain(
+        model, proposal_target_creator=cmr.models.utils.ProposalTargetCreator(n_sample=C['n_sample']))
+    chain.mask_branch_fg_only = False          # the reference evaluates the mask head on all RoIs
+    chain.to(dev).train()
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            assert tuple(p.shape) == P[name].shape, name
+            p.copy_(torch.from_numpy(P[name]))
+    np.random.seed(C['np_random_seed'])
+    loss = chain(torch.tensor(imgs, device=dev), bboxes, labels, masks, list(scales))
+    loss.backward()
+    torch.cuda.synchronize()
+    # integers: the proposals (decode, top-k order, NMS keep list), the sampled RoIs and their
+    # labels, and the position of the global np.random stream afterwards
+    # (the box COORDINATES are fp32 results of the RPN convolutions: within 1e-4 relative)
+    t = chain.last_targets
+    assert np.array_equal(t['gt_roi_labels'].cpu().numpy(), d['gt_roi_labels'])
+    assert np.array_equal(t['gt_roi_masks'].cpu().numpy(), d['gt_roi_masks'].astype(np.int32))
+    assert np.array_equal(t['gt_rpn_labels'].cpu().numpy(), d['gt_rpn_labels'].astype(np.int32))
+    assert int(np.random.randint(0, 2 ** 31 - 1)) == int(d['np_random_after'])
+    np.testing.assert_allclose(t['sample_rois'].cpu().numpy(), d['sample_rois'], rtol=1e-4, atol=1e-3)
+    # floats: the six reported scalars
+    rep = {k: float(v) for k, v in chain.report.items()}
+    for k, v in zip(d['loss_names'], d['loss_values']):
+        assert abs(rep[str(k)] - v) <= 1e-4 * max(abs(v), 1e-3), (k, rep[str(k)], v)
+    # gradients: norms of every trainable tensor, and a few small tensors element by element
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    for k, l2, mx in zip(d['grad_names'], d['grad_l2'], d['grad_absmax']):
+        g = grads[str(k)].detach().double()
+        assert abs(float(g.norm()) - l2) <= 1e-4 * l2 + 1e-12, (k, float(g.norm()), l2)
+    for key in d.files:
+        if key.startswith('grad/'):
+            ref = d[key]
+            got = grads[key[5:]].detach().cpu().numpy()
+            scale = np.abs(ref).max()
+            assert np.abs(got - ref).max() <= 1e-4 * scale, key

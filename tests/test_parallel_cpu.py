@@ -66,7 +66,7 @@ def test_bucketed_allreduce_gloo_world2():
 
 def test_arena_layout_and_stage_buckets():
     """ParamArena: 16-byte aligned slices in reverse registration order; values/grads are
-    views; DataParallelGradSync derives contiguous head+rpn / res4 / res3 buckets."""
+    views of the flat arenas; first-gradient claim / epoch bookkeeping."""
     from chainer_mask_rcnn_amd import optimizers
     torch.manual_seed(0)
 
@@ -93,6 +93,18 @@ def test_arena_layout_and_stage_buckets():
     m.c.grad.fill_(2.)
     assert float(arena.grads[:96].sum()) == 192.
     assert arena.slice_bounds(0, 1) == (0, 104)
+    # first gradient of a step may be written in place, a second one must be accumulated
+    assert arena.claim(m.a) and not arena.claim(m.a)
+    assert arena.written() == [False, False, True]        # arena order: c, b, a
+    arena.epoch += 1
+    assert arena.written() == [False, False, False] and arena.claim(m.a)
+    # a dropped / replaced .grad is detected and re-bound (its content folded in)
+    m.b.grad = None
+    m.a.grad = torch.ones_like(m.a)
+    assert not arena.claim(m.b)
+    arena.rebind()
+    assert arena.aliases(0) and arena.aliases(1) and arena.aliases(2)
+    assert float(m.a.grad.sum()) == 15. and m.a.grad.data_ptr() == arena.grads.data_ptr() + 4 * 104
 
 
 def _sync_worker(rank, world, port, q):
@@ -107,17 +119,14 @@ def _sync_worker(rank, world, port, q):
         def __init__(self, n):
             super().__init__()
             self.W = torch.nn.Parameter(torch.full((n,), float(rank + 1)))
-
-    class Ext(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.res3, self.res4 = Blk(8), Blk(12)
-            self.stage_hooks = {}
+            self.b = torch.nn.Parameter(torch.full((4,), float(rank + 1)))
 
     class Net(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.extractor, self.rpn, self.head = Ext(), Blk(5), Blk(20)
+            self.res3, self.res4, self.rpn, self.head = Blk(8), Blk(12), Blk(5), Blk(20)
+            self.frozen = torch.nn.Parameter(torch.full((6,), float(10 + rank)), requires_grad=False)
+            self.register_buffer('stat', torch.full((3,), float(20 + rank)))
 
     class Chain(torch.nn.Module):
         def __init__(self):
@@ -125,26 +134,56 @@ def _sync_worker(rank, world, port, q):
             self.mask_rcnn = Net()
             self.features_grad_hook = None
 
+    class Recording(parallel.TorchDistExchange):
+        def __init__(self):
+            super().__init__()
+            self.log = []
+
+        def allreduce_async(self, tensor, bucket_id=0):
+            self.log.append(bucket_id)
+            super().allreduce_async(tensor, bucket_id)
+
     chain = Chain()
     opt = optimizers.MomentumSGD(lr=0.1)
     opt.setup(chain)
-    sync = parallel.DataParallelGradSync(opt)
+    ex = Recording()
+    sync = parallel.DataParallelGradSync(opt, exchange=ex, bucket_bytes=64)
     opt._build()                                   # arena + attach (broadcast, buckets)
     a = opt.arena
+    net = chain.mask_rcnn
     ok = sync.world_size == world
-    # rank-0 weights everywhere
+    # bcast_data: rank-0 values everywhere, INCLUDING frozen parameters and buffers
     ok = ok and bool((a.values[a.values != 0] == 1.0).all())
-    # buckets: head+rpn | res4 | res3, contiguous, in backward order
-    ok = ok and len(sync.buckets.bounds) == 3 and sync.buckets.bounds[0][0] == 0
-    ok = ok and sync.buckets.bounds[-1][1] == a.size
-    ok = ok and chain.features_grad_hook is not None and 'res3' in chain.mask_rcnn.extractor.stage_hooks
-    # a "backward": every rank writes rank+1 into its gradients, hooks fire in stage order
-    a.grads.fill_(float(rank + 1))
-    chain.features_grad_hook(torch.zeros(1))
-    chain.mask_rcnn.extractor.stage_hooks['res3'](torch.zeros(1))
+    ok = ok and bool((net.frozen == 10.).all()) and bool((net.stat == 20.).all())
+    # buckets: cut at module boundaries (W and b of one module never separated), contiguous,
+    # in backward order (reverse registration: head, rpn, res4, res3), each >= 64 bytes
+    bp = sync.bucket_params
+    names = {id(p): n for n, p in chain.named_parameters()}
+    owners = [[names[id(p)].rsplit('.', 1)[0] for p in a.params[lo:hi + 1]] for lo, hi in bp]
+    ok = ok and owners == [['mask_rcnn.head', 'mask_rcnn.head'],
+                           ['mask_rcnn.rpn', 'mask_rcnn.rpn', 'mask_rcnn.res4', 'mask_rcnn.res4'],
+                           ['mask_rcnn.res3', 'mask_rcnn.res3']]
+    ok = ok and sync.buckets.bounds[0][0] == 0 and sync.buckets.bounds[-1][1] == a.size
+    ok = ok and all(sync.buckets.bounds[i][1] == sync.buckets.bounds[i + 1][0] for i in range(len(bp) - 1))
+    ok = ok and chain.features_grad_hook is not None
+    # a "backward": gradients appear head -> rpn -> res4 -> res3; a bucket is queued only once
+    # EVERY parameter in it has a gradient, and always in order
+    def write(mod):
+        for p in mod.parameters():
+            assert a.claim(p)
+            p.grad.fill_(float(rank + 1))
+    write(net.head); sync.poll()
+    ok = ok and ex.log == [0]
+    write(net.rpn); chain.features_grad_hook(torch.zeros(1))
+    ok = ok and ex.log == [0]                      # res4 shares the bucket: not ready yet
+    write(net.res4); sync.poll()
+    ok = ok and ex.log == [0, 1]
+    write(net.res3)                                # never polled: finish() launches the rest
     scale = sync.finish()
+    ok = ok and ex.log == [0, 1, 2]
     ok = ok and abs(scale - 1.0 / world) < 1e-12
-    ok = ok and bool((a.grads == float(sum(range(1, world + 1)))).all())
+    total = float(sum(range(1, world + 1)))
+    ok = ok and all(bool((p.grad == total).all()) for p in a.params)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
