@@ -13,8 +13,9 @@ configs[1]: batch 2 x 800x1333 fp32 per GPU, 512 RoIs/img, 81 classes.  Inputs a
 resident in HBM before the timed region.  Weak scaling: every rank runs its own batch of 2.
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel,
-HIP-event timed inside the run) and `cpu_baseline` (the oracle's NumPy/BLAS conv path
-timed on the host cores on a bounded sample, reported only).
+HIP-event timed inside the run), `rotating_h2d` (the same step over rotating host batches with
+the image upload inside the timed region) and `cpu_baseline` (the oracle's restated Chainer CPU
+path timed on the host cores on BASELINE configs[0] in full, reported only).
 """
 import argparse
 import ctypes
@@ -145,47 +146,48 @@ def pmc_traffic(kernel_name):
     return None
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle ("port") timed on the host cores on a bounded sample of the same workload:
-    forward + dgrad + wgrad of one res5 bottleneck (b1: 1x1 2048->512, 3x3 512->512,
-    1x1 512->2048 on 7x7 maps) through the oracle's im2col + BLAS path (what chainer's CPU
-    path does), on as many RoIs as fit the time budget; scaled to a whole
-    train step by algorithmic FLOPs."""
+def cpu_baseline():
+    """The oracle ("port": oracle/np_step.py, the restated Chainer CPU path — NumPy im2col +
+    BLAS convolutions, C ROIAlign, chainercv-style proposal / target creators, hand-written
+    backward) timed on this node's host cores on BASELINE configs[0] IN FULL: one 800 x 1333
+    image, 512 sampled RoIs, forward + backward, ONE timed iteration after a small warm-up
+    iteration (BLAS thread pool, imports).  Nothing is extrapolated.  Reported only."""
     import oracle  # noqa: F401  (test infrastructure; used here only as the timed baseline)
-    from oracle import np_ref
-    rng = np.random.RandomState(0)
-    R = 32
-    x = rng.standard_normal((R, 2048, 7, 7)).astype(np.float32)
-    W1 = (rng.standard_normal((512, 2048, 1, 1)) * 0.02).astype(np.float32)
-    W2 = (rng.standard_normal((512, 512, 3, 3)) * 0.02).astype(np.float32)
-    W3 = (rng.standard_normal((2048, 512, 1, 1)) * 0.02).astype(np.float32)
-
-    def run():
-        h1 = np.maximum(np_ref.conv2d_fwd(x, W1), 0)
-        h2 = np.maximum(np_ref.conv2d_fwd(h1, W2, None, 1, 1), 0)
-        y = np_ref.conv2d_fwd(h2, W3)
-        g3, _, _ = np_ref.conv2d_bwd(h2, W3, y)
-        g2, _, _ = np_ref.conv2d_bwd(h1, W2, g3 * (h2 > 0), 1, 1)
-        np_ref.conv2d_bwd(x, W1, g2 * (h1 > 0))
-
-    gflop_per_roi = 3 * 2 * 49 * (2048 * 512 + 512 * 512 * 9 + 512 * 2048) / 1e9
-    run()  # warm-up (BLAS thread pool)
-    t0 = time.time()
-    reps = 0
-    while True:
-        run()
-        reps += 1
-        if time.time() - t0 > seconds_budget or reps >= 50:
-            break
-    dt = time.time() - t0
-    gflops = gflop_per_roi * R * reps / dt
-    sec_per_image = TRAIN_GFLOP_PER_IMAGE[50] / gflops
-    return dict(value=1.0 / sec_per_image, unit='images/sec', cores=os.cpu_count(),
-                kind='port',
-                sample=('oracle np_ref (im2col+BLAS) fwd+dgrad+wgrad of res5.b1 on %d RoIs x %d '
-                        'reps = %.1f s, %.1f GFLOP/s on %d threads, scaled by 3157 GFLOP/img; '
-                        'the literal reference ROIAlign CPU loop (5-24 us/element) would add '
-                        '~1e3 s per image' % (R, reps, dt, gflops, os.cpu_count())))
+    from oracle import np_step
+    oracle.build()
+    state = np.random.get_state()
+    P = np_step.synthetic_params(50)
+    w_in = np_step.synthetic_inputs(1, 1, 160, 224, n_gt=3, scale=1.0)
+    np.random.seed(0)
+    np_step.train_step(P, *w_in, n_sample=32, proposal_creator_params=dict(
+        min_size=0, n_train_pre_nms=600, n_train_post_nms=100))          # warm-up (not timed)
+    inputs = np_step.synthetic_inputs(0, 1, 800, 1333)
+    np.random.seed(0)
+    tm = {}
+    t0 = time.perf_counter()
+    out = np_step.train_step(P, *inputs, timings=tm)
+    dt = time.perf_counter() - t0
+    np.random.set_state(state)
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [i['num_threads'] for i in threadpool_info() if i.get('user_api') == 'blas']
+        if blas:
+            threads = max(blas)
+    except Exception:
+        pass
+    prev, phases = 0., {}
+    for k, v in tm.items():
+        phases[k] = round(v - prev, 2)
+        prev = v
+    return dict(value=1.0 / dt, unit='images/sec', cores=threads, kind='port',
+                seconds_per_iteration=round(dt, 2),
+                sample=('measured C1: BASELINE configs[0] in full — 1 x 800x1333 image, %d sampled '
+                        'RoIs, forward + backward through oracle/np_step.py (NumPy im2col + BLAS on '
+                        '%d threads of %d logical cores, single-threaded C ROIAlign / NMS), 1 timed '
+                        'iteration after a 160x224 warm-up iteration; loss %.4f; seconds per phase: %s'
+                        % (len(out['gt_roi_labels']), threads, os.cpu_count(), out['losses']['loss'],
+                           phases)))
 
 
 def bench_infer(args, device, rank):

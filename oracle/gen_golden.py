@@ -339,7 +339,102 @@ def main():
     #      stored; inputs and weights are regenerated from the seeds by np_step.synthetic_*.
     from oracle import np_step
     np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **train_step_fixture(np_step))
+    # (11) Detectron -> chainer weight mapping: the reference converter's OWN assignment
+    #      statements (examples/coco/convert_caffe2_to_chainer.py:46-249) executed on seeded
+    #      synthetic blobs of the real shapes; position-sensitive checksums of every destination
+    #      array are stored (the arrays themselves are 170 MB).
+    np.savez_compressed(os.path.join(OUT, 'detectron_convert.npz'), **detectron_fixture())
     print('golden vectors written to', os.path.normpath(OUT))
+
+
+def detectron_blobs(seed=5, n_layers=50):
+    """Seeded stand-in for Detectron's `model_final.pkl['blobs']`: every blob the converter
+    reads, with its real shape, plus the kinds it must ignore (momentum, fc1000, conv biases)."""
+    import zlib
+    blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[n_layers]
+    shapes = {'conv1_w': (64, 3, 7, 7), 'conv1_b': (64,), 'res_conv1_bn_s': (64,),
+              'res_conv1_bn_b': (64,), 'conv_rpn_w': (1024, 1024, 3, 3), 'conv_rpn_b': (1024,),
+              'rpn_bbox_pred_w': (60, 1024, 1, 1), 'rpn_bbox_pred_b': (60,),
+              'rpn_cls_logits_w': (15, 1024, 1, 1), 'rpn_cls_logits_b': (15,),
+              'cls_score_w': (81, 2048), 'cls_score_b': (81,), 'bbox_pred_w': (324, 2048),
+              'bbox_pred_b': (324,), 'conv5_mask_w': (2048, 256, 2, 2), 'conv5_mask_b': (256,),
+              'mask_fcn_logits_w': (81, 256, 1, 1), 'mask_fcn_logits_b': (81,),
+              'fc1000_w': (10, 2048), 'fc1000_b': (10,), 'conv1_w_momentum': (64, 3, 7, 7)}
+    cin = 64
+    for stage, n, mid, cout in zip((2, 3, 4, 5), blocks, (64, 128, 256, 512), (256, 512, 1024, 2048)):
+        for i in range(n):
+            ci = cin if i == 0 else cout
+            pre = 'res%d_%d_' % (stage, i)
+            for br, shp in (('branch2a', (mid, ci, 1, 1)), ('branch2b', (mid, mid, 3, 3)),
+                            ('branch2c', (cout, mid, 1, 1))) + \
+                    ((('branch1', (cout, ci, 1, 1)),) if i == 0 else ()):
+                shapes[pre + br + '_w'] = shp
+                shapes[pre + br + '_bn_s'] = (shp[0],)
+                shapes[pre + br + '_bn_b'] = (shp[0],)
+                shapes[pre + br + '_b'] = (shp[0],)
+        cin = cout
+    blobs = {}
+    for k, shp in shapes.items():
+        rng = np.random.RandomState((zlib.crc32(k.encode()) + seed) % (2 ** 31))
+        blobs[k] = rng.standard_normal(shp).astype(np.float32)
+    return blobs
+
+
+def array_checksums(a):
+    """(sum, sum of squares, position-weighted sum) in float64: any permutation, flip or slice
+    error changes at least the third."""
+    v = np.asarray(a, np.float64).ravel()
+    w = ((np.arange(v.size, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1000003)).astype(np.float64) / 1e6
+    return np.array([v.sum(), (v * v).sum(), (v * w).sum()])
+
+
+def detectron_fixture():
+    import ast
+    path = '/root/reference/examples/coco/convert_caffe2_to_chainer.py'
+    tree = ast.parse(open(path).read())
+    body, on = [], False
+    for node in tree.body:
+        tgt = node.targets[0].id if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) else None
+        if tgt == 'params_src':
+            break
+        if on:
+            body.append(node)
+        if tgt == 'model':
+            on = True
+    blobs = detectron_blobs()
+
+    class Leaf(object):
+        def __init__(self, shape):
+            self.data = np.full(shape, np.nan, np.float32)
+
+    class Node(object):
+        pass
+    from oracle import np_step
+    shapes = dict(np_step.param_shapes(50))
+    for k in ('rpn.loc_score.W', 'rpn.loc_score.b', 'head.cls_loc_score.W', 'head.cls_loc_score.b'):
+        del shapes[k]
+    shapes.update({'rpn.loc.W': (60, 1024, 1, 1), 'rpn.loc.b': (60,), 'rpn.score.W': (15, 1024, 1, 1),
+                   'rpn.score.b': (15,), 'head.cls_loc.W': (324, 2048), 'head.cls_loc.b': (324,),
+                   'head.score.W': (81, 2048), 'head.score.b': (81,)})
+    model = Node()
+    for name, shp in shapes.items():
+        cur = model
+        parts = name.split('.')
+        for part in parts[:-1]:
+            if not hasattr(cur, part):
+                setattr(cur, part, Node())
+            cur = getattr(cur, part)
+        setattr(cur, parts[-1], Leaf(shp))
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, 'exec'),
+         {'np': np, 'blobs': blobs, 'model': model})
+    fx = {}
+    for name in sorted(shapes):
+        cur = model
+        for part in name.split('.'):
+            cur = getattr(cur, part)
+        assert not np.isnan(cur.data).any(), name + ' was not filled by the reference converter'
+        fx[name.replace('.', '/')] = array_checksums(cur.data)
+    return fx
 
 
 TRAIN_STEP_CFG = dict(n_layers=50, H=160, W=224, batch=2, n_gt=3, n_sample=32, input_seed=3,

@@ -81,3 +81,46 @@ def test_pretrained_model_argument(model, tmp_path):
         cmr.models.MaskRCNNResNet(34, n_fg_class=80)
     with pytest.raises(ValueError):
         cmr.models.MaskRCNNResNet(50, n_fg_class=80, mean=(1., 2.))
+
+
+def test_detectron_mapping_matches_reference_converter(model, golden_dir):
+    """serializers.detectron_to_chainer / load_detectron vs tests/golden/detectron_convert.npz:
+    checksums of every destination array as filled by the REFERENCE converter's own assignment
+    statements (examples/coco/convert_caffe2_to_chainer.py:46-249, executed by
+    oracle/gen_golden.py section 11) on the same seeded synthetic blobs: BGR->RGB flip of conv1,
+    (dx,dy,dw,dh)->(dy,dx,dh,dw) row permutations of both box regressors, dropped background
+    mask channel, ignored momentum / fc1000 / conv-bias blobs."""
+    from oracle.gen_golden import detectron_blobs, array_checksums
+    d = np.load(os.path.join(golden_dir, 'detectron_convert.npz'))
+    blobs = detectron_blobs()
+    arrays = serializers.detectron_to_chainer(blobs, 50)
+    assert set(arrays) == set(d.files)
+    for k in d.files:
+        assert arrays[k].dtype == np.float32
+        assert np.array_equal(array_checksums(arrays[k]), d[k]), k
+    # the checksum notices each of the transformations
+    assert not np.array_equal(array_checksums(blobs['conv1_w']), d['extractor/conv1/W'])
+    assert not np.array_equal(array_checksums(blobs['bbox_pred_w']), d['head/cls_loc/W'])
+    assert not np.array_equal(array_checksums(blobs['rpn_bbox_pred_b']), d['rpn/loc/b'])
+    assert arrays['head/mask/W'].shape == (80, 256, 1, 1)
+    # into the model (fused filters assembled), and back out through the snapshot contract
+    serializers.load_detectron(blobs, model)
+    back = serializers.state_arrays(model)
+    for k in d.files:
+        assert np.array_equal(back[k], arrays[k]), k
+    assert np.array_equal(model.extractor.conv1.W.detach().numpy()[:, 0], blobs['conv1_w'][:, 2])
+    assert serializers.DETECTRON_MEAN == (122.7717, 115.9465, 102.9801)
+
+
+def test_detectron_mapping_resnet101_names():
+    """The rule form of the mapping covers ResNet-101's 23 res4 blocks (res4_0 .. res4_22)."""
+    from oracle.gen_golden import detectron_blobs
+    blobs = detectron_blobs(n_layers=101)
+    arrays = serializers.detectron_to_chainer(blobs, 101)
+    assert 'extractor/res4/b22/conv3/W' in arrays and 'extractor/res4/b23/conv1/W' not in arrays
+    assert np.array_equal(arrays['extractor/res4/b22/conv2/W'], blobs['res4_22_branch2b_w'])
+    m = cmr.models.MaskRCNNResNet(101, n_fg_class=80, anchor_scales=(2, 4, 8, 16, 32), roi_size=14)
+    serializers.load_detectron(blobs, m)
+    assert np.array_equal(m.extractor.res4.b22.bn3.W.detach().numpy(), blobs['res4_22_branch2c_bn_s'])
+    with pytest.raises(KeyError):
+        serializers.detectron_to_chainer(detectron_blobs(n_layers=50), 101)
