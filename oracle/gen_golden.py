@@ -344,7 +344,80 @@ def main():
     #      synthetic blobs of the real shapes; position-sensitive checksums of every destination
     #      array are stored (the arrays themselves are 170 MB).
     np.savez_compressed(os.path.join(OUT, 'detectron_convert.npz'), **detectron_fixture())
+    # (12) COCO annotation decoding: the reference's own `_annotations_to_example`
+    #      (datasets/coco.py:123-176) and `utils.mask_to_bbox` (utils/geometry.py:150-166) executed
+    #      on a synthetic annotation list (polygons through the real PIL.ImageDraw; run-length
+    #      masks through the oracle's restatement of pycocotools.mask, which is not installable).
+    np.savez_compressed(os.path.join(OUT, 'coco_example.npz'), **coco_fixture())
     print('golden vectors written to', os.path.normpath(OUT))
+
+
+def coco_annotations(height=60, width=80):
+    """A synthetic COCO annotation list covering every branch of _annotations_to_example."""
+    from oracle import np_data
+    rng = np.random.RandomState(8)
+    blob = np.zeros((height, width), np.uint8)
+    blob[10:30, 20:50] = 1
+    blob[15:20, 25:30] = 0
+    ring = np.zeros((height, width), np.uint8)
+    yy, xx = np.mgrid[0:height, 0:width]
+    ring[((yy - 30) ** 2 + (xx - 40) ** 2 < 400) & ((yy - 30) ** 2 + (xx - 40) ** 2 > 100)] = 1
+    noise = (rng.uniform(size=(height, width)) > 0.7).astype(np.uint8)
+    return [
+        dict(id=1, image_id=7, category_id=18, iscrowd=0, area=300.5,
+             segmentation=[[5.0, 5.0, 40.5, 8.0, 30.0, 30.25, 8.0, 25.0],
+                           [50.0, 40.0, 70.0, 42.0, 60.0, 55.0]]),
+        dict(id=2, image_id=7, category_id=1, iscrowd=1, area=float(blob.sum()),
+             segmentation=dict(size=[height, width], counts=np_data.mask_to_rle_counts(blob))),
+        dict(id=3, image_id=7, category_id=44, iscrowd=0, area=float(ring.sum()),
+             segmentation=dict(size=[height, width],
+                               counts=np_data.rle_to_string(np_data.mask_to_rle_counts(ring)))),
+        dict(id=4, image_id=7, category_id=3, iscrowd=0, area=1.0),            # no segmentation
+        dict(id=5, image_id=7, category_id=3, iscrowd=0, area=float(noise.sum()),
+             segmentation=dict(size=[height, width],
+                               counts=np_data.rle_to_string(np_data.mask_to_rle_counts(noise)))),
+        dict(id=6, image_id=7, category_id=90, iscrowd=0, area=4.0,            # malformed size
+             segmentation=dict(size=[height - 1, width], counts=[0, (height - 1) * width])),
+    ]
+
+
+COCO_CATEGORIES = [dict(id=i, name='cat%d' % i) for i in (90, 1, 3, 18, 44)]
+
+
+def coco_fixture():
+    import json
+    import PIL.Image
+    import PIL.ImageDraw
+    from oracle import np_data
+    H, W = 60, 80
+    anns = coco_annotations(H, W)
+    base = '/root/reference/chainer_mask_rcnn'
+    import ast
+
+    def ref_function(path, name, namespace):
+        tree = ast.parse(open(path).read())
+        node = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == name][0]
+        exec(compile(ast.Module(body=[node], type_ignores=[]), path, 'exec'), namespace)
+        return namespace[name]
+    mask_to_bbox = ref_function(os.path.join(base, 'utils', 'geometry.py'), 'mask_to_bbox', {'np': np})
+    pyco = types.SimpleNamespace(mask=types.SimpleNamespace(
+        frPyObjects=lambda segs, h, w: list(segs),
+        decode=lambda rles: np.stack([np_data.rle_decode(r) for r in rles], axis=2)))
+    ns = {'np': np, 'PIL': PIL, 'pycocotools': pyco,
+          'utils': types.SimpleNamespace(mask_to_bbox=mask_to_bbox)}
+    fn = ref_function(os.path.join(base, 'datasets', 'coco.py'), '_annotations_to_example', ns)
+    cat_ids = {c['id']: i for i, c in enumerate(sorted(COCO_CATEGORIES, key=lambda x: x['id']))}
+    fx = {'annotations_json': np.array(json.dumps(anns)), 'height': H, 'width': W,
+          'categories_json': np.array(json.dumps(COCO_CATEGORIES))}
+    for tag, use_crowd in (('nocrowd', False), ('crowd', True)):
+        self = types.SimpleNamespace(_use_crowd=use_crowd, _return_crowd=True, _return_area=True,
+                                     cat_id_to_class_id=cat_ids)
+        bboxes, labels, masks, crowds, areas = fn(self, anns, H, W)
+        fx.update({tag + '_bboxes': bboxes, tag + '_labels': labels,
+                   tag + '_masks': np.packbits(masks.astype(np.uint8), axis=-1),
+                   tag + '_masks_shape': np.array(masks.shape), tag + '_crowds': crowds,
+                   tag + '_areas': areas})
+    return fx
 
 
 def detectron_blobs(seed=5, n_layers=50):

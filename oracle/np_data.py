@@ -70,3 +70,78 @@ def concat_padded(arrays, padding):
     for i, a in enumerate(arrays):
         out[(i,) + tuple(slice(0, d) for d in a.shape)] = a
     return out
+
+
+# --------------------------------------------------------------------------------------
+# pycocotools.mask restatement (un-vendored dependency of datasets/coco.py:145-151; algorithm:
+# cocoapi common/maskApi.c rleFrString / rleDecode): "parity unpinned".
+# --------------------------------------------------------------------------------------
+
+def rle_from_string(s):
+    """compressed COCO RLE string -> list of run lengths."""
+    if isinstance(s, str):
+        s = s.encode('ascii')
+    cnts = []
+    p = 0
+    while p < len(s):
+        x = 0
+        k = 0
+        more = 1
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1f) << 5 * k
+            more = c & 0x20
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << 5 * k
+        if len(cnts) > 2:
+            x += cnts[len(cnts) - 2]
+        cnts.append(x)
+    return cnts
+
+
+def rle_to_string(cnts):
+    """list of run lengths -> compressed COCO RLE string (maskApi.c rleToString): the inverse,
+    used to build test annotations."""
+    out = bytearray()
+    for i, x in enumerate(cnts):
+        x = int(x)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            c = x & 0x1f
+            x >>= 5
+            more = (x != -1) if (c & 0x10) else (x != 0)
+            if more:
+                c |= 0x20
+            out.append(c + 48)
+    return bytes(out).decode('ascii')
+
+
+def mask_to_rle_counts(mask):
+    """(h, w) {0,1} mask -> uncompressed COCO counts (column-major runs starting with zeros)."""
+    flat = np.asarray(mask, np.uint8).T.reshape(-1)
+    cnts, v, run = [], 0, 0
+    for b in flat:
+        if b != v:
+            cnts.append(run)
+            run, v = 0, b
+        run += 1
+    cnts.append(run)
+    return cnts
+
+
+def rle_decode(rle):
+    """{'counts': list | str, 'size': [h, w]} -> (h, w) uint8 (pycocotools.mask.decode)."""
+    h, w = rle['size']
+    cnts = rle['counts'] if isinstance(rle['counts'], (list, tuple)) else rle_from_string(rle['counts'])
+    out = np.zeros(h * w, np.uint8)
+    pos, v = 0, 0
+    for c in cnts:
+        for _ in range(c):
+            out[pos] = v
+            pos += 1
+        v = 1 - v
+    return out.reshape(w, h).transpose(1, 0)
