@@ -89,6 +89,15 @@ SIGNATURES = {
                                       c_vp]),
     'mrcnn_sgd_momentum_wd_ex': (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32,
                                          c_int, c_vp]),
+    'mrcnn_bbox_iou_argmax': (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'mrcnn_anchor_labels': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_f32, c_vp, c_vp]),
+    'mrcnn_anchor_targets_finish': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int,
+                                            c_int, c_vp, c_vp, c_vp]),
+    'mrcnn_proposal_targets_gather': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
+                                              ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),
+                                              c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'mrcnn_mask_targets': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int,
+                                   c_vp, c_vp]),
     'mrcnn_allreduce_unique_id': (c_int, [c_vp]),
     'mrcnn_allreduce_init': (c_int, [c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
     'mrcnn_allreduce_destroy': (c_int, [c_vp]),

@@ -81,6 +81,12 @@ class MaskRCNNTrainChain(torch.nn.Module):
         self.report = {}
         self.features_grad_hook = None     # set by parallel.DataParallelGradSync
         self.mask_branch_fg_only = True
+        # run the arithmetic of both target creators as HIP kernels
+        # (IoU matrices, label rules, regression targets, mask targets when the ground-truth
+        # masks are device tensors); the np.random draws stay on the host, in the reference's
+        # order, so the sampled sets are identical.  Off by default: at COCO sizes the host
+        # creators already overlap with the GPU and the device path adds read-backs.
+        self.device_targets = False
         self.host_timeline = None          # developer aid: list of (label, perf_counter) marks
 
     def forward(self, imgs, bboxes, labels, masks, scales):
@@ -107,6 +113,56 @@ class MaskRCNNTrainChain(torch.nn.Module):
         # start it on worker threads now (NumPy releases the GIL) so it overlaps with the
         # GPU's extractor/RPN/head work; its np.random draws happen later, in order.
         anchor_h = self.mask_rcnn.rpn.host_anchor(features.shape[2], features.shape[3], dev)
+        atc = self.anchor_target_creator
+        ptc = self.proposal_target_creator
+        if self.device_targets and dev.type == 'cuda' and hasattr(ptc, 'sample_device') \
+                and hasattr(atc, 'prepare_device'):
+            (rpn_locs, rpn_scores, sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels,
+             gt_roi_masks, gt_rpn_locs, gt_rpn_labels, roi_cls_locs, roi_scores, roi_masks,
+             mask_rows) = self._forward_device_targets(
+                features, img_size, scales, bboxes, labels, masks, anchor_h, mark)
+        else:
+            (rpn_locs, rpn_scores, sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels,
+             gt_roi_masks, gt_rpn_locs, gt_rpn_labels, roi_cls_locs, roi_scores, roi_masks,
+             mask_rows) = self._forward_host_targets(
+                features, img_size, scales, bboxes, labels, masks, anchor_h, mark)
+        rpn_locs = rpn_locs.reshape(-1, 4)
+        rpn_scores = rpn_scores.reshape(-1)
+        rpn_loc_loss = F.fast_rcnn_loc_loss(rpn_locs, gt_rpn_locs, gt_rpn_labels, self.rpn_sigma)
+        rpn_cls_loss = F.sigmoid_cross_entropy(rpn_scores, gt_rpn_labels)
+
+        # Losses for outputs of the head: the class-specific 4-vector is selected inside
+        # the kernel (roi_cls_locs[arange(n), gt_roi_labels], :168-170).
+        roi_loc_loss = F.fast_rcnn_loc_loss(
+            roi_cls_locs, gt_roi_locs, gt_roi_labels, self.roi_sigma, cls=gt_roi_labels)
+        roi_cls_loss = F.softmax_cross_entropy(roi_scores, gt_roi_labels)
+
+        # Losses for outputs of mask branch (:176-178)
+        if mask_rows is not None:
+            roi_mask_loss = F.mask_sigmoid_cross_entropy(
+                roi_masks, gt_roi_labels.index_select(0, mask_rows),
+                gt_roi_masks.index_select(0, mask_rows))
+        else:
+            roi_mask_loss = F.mask_sigmoid_cross_entropy(roi_masks, gt_roi_labels, gt_roi_masks)
+
+        loss = rpn_loc_loss + rpn_cls_loss + roi_loc_loss + roi_cls_loss + roi_mask_loss
+        self.report = {'rpn_loc_loss': rpn_loc_loss.detach(),
+                       'rpn_cls_loss': rpn_cls_loss.detach(),
+                       'roi_loc_loss': roi_loc_loss.detach(),
+                       'roi_cls_loss': roi_cls_loss.detach(),
+                       'roi_mask_loss': roi_mask_loss.detach(),
+                       'loss': loss.detach()}
+        mark('losses queued')
+        self.last_targets = {'sample_rois': sample_rois, 'gt_roi_labels': gt_roi_labels,
+                             'gt_roi_masks': gt_roi_masks, 'gt_rpn_labels': gt_rpn_labels,
+                             'n_rois': int(sample_rois.shape[0])}
+        return loss
+
+    def _forward_host_targets(self, features, img_size, scales, bboxes, labels, masks, anchor_h, mark):
+        """RPN, host target creators (the reference's arrangement, :126-158) and the RoI head."""
+        dev = features.device
+        batch_size = features.shape[0]
+        to_np = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
         atc = self.anchor_target_creator
         atc_jobs = None
         if hasattr(atc, 'prepare') and hasattr(atc, 'finish'):
@@ -192,34 +248,78 @@ class MaskRCNNTrainChain(torch.nn.Module):
             [np.concatenate(gt_rpn_locs, axis=0), np.concatenate(gt_rpn_labels, axis=0)],
             [torch.float32, torch.int32], dev)
         mark('rpn targets')
-        rpn_locs = rpn_locs.reshape(-1, 4)
-        rpn_scores = rpn_scores.reshape(-1)
-        rpn_loc_loss = F.fast_rcnn_loc_loss(rpn_locs, gt_rpn_locs, gt_rpn_labels, self.rpn_sigma)
-        rpn_cls_loss = F.sigmoid_cross_entropy(rpn_scores, gt_rpn_labels)
+        return (rpn_locs, rpn_scores, sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels,
+                gt_roi_masks, gt_rpn_locs, gt_rpn_labels, roi_cls_locs, roi_scores, roi_masks, mask_rows)
 
-        # Losses for outputs of the head: the class-specific 4-vector is selected inside
-        # the kernel (roi_cls_locs[arange(n), gt_roi_labels], :168-170).
-        roi_loc_loss = F.fast_rcnn_loc_loss(
-            roi_cls_locs, gt_roi_locs, gt_roi_labels, self.roi_sigma, cls=gt_roi_labels)
-        roi_cls_loss = F.softmax_cross_entropy(roi_scores, gt_roi_labels)
-
-        # Losses for outputs of mask branch (:176-178)
-        if mask_rows is not None:
-            roi_mask_loss = F.mask_sigmoid_cross_entropy(
-                roi_masks, gt_roi_labels.index_select(0, mask_rows),
-                gt_roi_masks.index_select(0, mask_rows))
-        else:
-            roi_mask_loss = F.mask_sigmoid_cross_entropy(roi_masks, gt_roi_labels, gt_roi_masks)
-
-        loss = rpn_loc_loss + rpn_cls_loss + roi_loc_loss + roi_cls_loss + roi_mask_loss
-        self.report = {'rpn_loc_loss': rpn_loc_loss.detach(),
-                       'rpn_cls_loss': rpn_cls_loss.detach(),
-                       'roi_loc_loss': roi_loc_loss.detach(),
-                       'roi_cls_loss': roi_cls_loss.detach(),
-                       'roi_mask_loss': roi_mask_loss.detach(),
-                       'loss': loss.detach()}
-        mark('losses queued')
-        self.last_targets = {'sample_rois': sample_rois, 'gt_roi_labels': gt_roi_labels,
-                             'gt_roi_masks': gt_roi_masks, 'gt_rpn_labels': gt_rpn_labels,
-                             'n_rois': int(sample_rois.shape[0])}
-        return loss
+    def _forward_device_targets(self, features, img_size, scales, bboxes, labels, masks, anchor_h,
+                                mark):
+        """Same step with the target arithmetic on the device.  The
+        np.random call order is the reference's: every ProposalTargetCreator draw (foreground,
+        background, image by image), then every AnchorTargetCreator draw."""
+        dev = features.device
+        batch_size = features.shape[0]
+        atc, ptc = self.anchor_target_creator, self.proposal_target_creator
+        anchor_d = self.mask_rcnn.rpn._anchor(features.shape[2], features.shape[3], dev)[1]
+        # RPN label rule: needs only the ground truth -> queued ahead of the RPN itself; the
+        # labels travel to pinned host memory asynchronously
+        atc_states = [atc.prepare_device(bbox, anchor_d, anchor_h, img_size, upload=_upload)
+                      for bbox in bboxes]
+        rpn_locs, rpn_scores, rois, roi_indices, anchor = self.mask_rcnn.rpn(
+            features, img_size, scales)
+        mark('extractor+rpn queued')
+        pc = getattr(self.mask_rcnn.rpn, 'proposal_layer', None)
+        counts = getattr(pc, 'last_counts', None)
+        if counts is None:
+            counts = np.bincount(roi_indices.cpu().numpy(), minlength=batch_size).tolist()
+        bounds = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+        mark('rois on host')
+        s_rois, s_idx, g_locs, g_labels, jobs = [], [], [], [], []
+        for i, (bbox, label) in enumerate(zip(bboxes, labels)):
+            roi_i = rois[int(bounds[i]):int(bounds[i + 1])]
+            sample_roi, gt_roi_loc, gt_roi_label, job = ptc.sample_device(roi_i, bbox, label,
+                                                                          upload=_upload)
+            mark('ptc.sample')
+            s_rois.append(sample_roi)
+            s_idx.append(torch.full((job['n'],), i, dtype=torch.int32, device=dev))
+            g_locs.append(gt_roi_loc)
+            g_labels.append(gt_roi_label)
+            jobs.append(job)
+        sample_rois, sample_roi_indices = torch.cat(s_rois, 0), torch.cat(s_idx, 0)
+        gt_roi_locs, gt_roi_labels = torch.cat(g_locs, 0), torch.cat(g_labels, 0)
+        offs = np.concatenate([[0], np.cumsum([j['n'] for j in jobs])]).astype(int)
+        fg_rows = np.concatenate([np.arange(offs[i], offs[i] + j['n_fg']) for i, j in enumerate(jobs)]) \
+            if self.mask_branch_fg_only else np.zeros(0, np.int64)
+        # ground-truth masks that live on the host: their 14x14 targets are built there (as in
+        # the host path) from the foreground boxes, read back BEFORE the head is queued
+        host_mask = [not (isinstance(m, torch.Tensor) and m.is_cuda) for m in masks]
+        fg_boxes_h = {}
+        for i, j in enumerate(jobs):
+            if host_mask[i] and j['n_fg'] > 0:
+                fg_boxes_h[i] = (j['sample_roi'][:j['n_fg']].cpu().numpy(),
+                                 j['gt_index'][:j['n_fg']].cpu().numpy())
+        mark('rois sampled')
+        mask_rows = None
+        if self.mask_branch_fg_only and len(fg_rows) > 0:
+            mask_rows = _upload(np.asarray(fg_rows, np.int64), torch.int64, dev)
+        roi_cls_locs, roi_scores, roi_masks = self.mask_rcnn.head(
+            features, sample_rois, sample_roi_indices, mask_rows=mask_rows)
+        mark('head queued')
+        from .utils.proposal_target_creator import _mask_targets
+        parts = []
+        for i, (j, m) in enumerate(zip(jobs, masks)):
+            if not host_mask[i]:
+                parts.append(ptc.mask_targets_device(j, m))
+                continue
+            t = -np.ones((j['n'], ptc.mask_size, ptc.mask_size), dtype=np.int32)
+            if j['n_fg'] > 0:
+                boxes, gt_index = fg_boxes_h[i]
+                t[:j['n_fg']] = _mask_targets(np.round(boxes).astype(np.int32), gt_index,
+                                              np.asarray(m), ptc.mask_size)
+            parts.append(_upload(t, torch.int32, dev))
+        gt_roi_masks = torch.cat(parts, 0)
+        mark('mask targets')
+        g_rl, g_rlab = zip(*[atc.finish_device(st) for st in atc_states])
+        gt_rpn_locs, gt_rpn_labels = torch.cat(g_rl, 0), torch.cat(g_rlab, 0)
+        mark('rpn targets')
+        return (rpn_locs, rpn_scores, sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels,
+                gt_roi_masks, gt_rpn_locs, gt_rpn_labels, roi_cls_locs, roi_scores, roi_masks, mask_rows)

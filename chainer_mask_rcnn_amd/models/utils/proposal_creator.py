@@ -23,6 +23,7 @@ class ProposalCreator(object):
         self.train = True                    # chainer.config.train
         self.keep_host_copy = False          # set by MaskRCNNTrainChain (see batch())
         self.last_host_rois = None
+        self.last_counts = None              # per-image proposal counts of the last batch()
 
     def __call__(self, loc, score, anchor, img_size, scale=1., return_indices=False):
         """loc (S,4), score (S,), anchor (S,4) device tensors -> roi (R,4) device tensor."""
@@ -82,5 +83,6 @@ class ProposalCreator(object):
         else:
             n_keep = n_keep.cpu().tolist()       # the one host synchronisation
             self.last_host_rois = None
+        self.last_counts = list(n_keep)
         return [P.gather_rows(sorted_rois[i], keep[i, :n_keep[i]].contiguous())
                 for i in range(n)]

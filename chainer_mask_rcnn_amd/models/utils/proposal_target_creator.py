@@ -77,6 +77,60 @@ class ProposalTargetCreator(object):
         job = (len(sample_roi), n_fg, np.round(sample_roi[:n_fg]).astype(np.int32), assigned[fg])
         return sample_roi, gt_roi_loc, gt_roi_label, job
 
+    # ------------------------------------------------------------------ device half (8f-3)
+    def sample_device(self, roi, bbox, label, loc_normalize_mean=(0., 0., 0., 0.),
+                      loc_normalize_std=(0.1, 0.1, 0.2, 0.2), upload=None):
+        """``sample`` with the arithmetic on the device: roi (R,4) is a
+        DEVICE tensor, bbox / label host arrays.  The IoU matrix, its row max / argmax, the
+        gather of the chosen candidates, labels and normalised regression targets run as HIP
+        kernels; only the per-candidate max IoU comes back to the host, where the SAME
+        ``np.random.choice`` calls as ``sample`` pick the rows (foreground first, then
+        background).  Returns device tensors sample_roi (S,4), gt_roi_loc (S,4), gt_roi_label
+        (S,) and a job for ``mask_targets_device``; ``job['n_fg']`` / ``job['n']`` are host ints."""
+        import torch
+        from ...functions import target_ops as T
+        bbox = np.asarray(bbox, np.float32)
+        label = np.asarray(label)
+        if bbox.shape[0] == 0:
+            raise ValueError('Empty bbox is not supported.')
+        dev = roi.device
+        if upload is None:
+            upload = lambda a, dt, d: torch.tensor(a, dtype=dt, device=d)
+        bbox_d = upload(bbox, torch.float32, dev)
+        label_d = upload(label.astype(np.int32), torch.int32, dev)
+        cand = torch.cat((roi.detach().to(torch.float32), bbox_d), dim=0).contiguous()   # :121
+        best_d, assigned_d = T.bbox_iou_argmax(cand, bbox_d)
+        best = best_d.cpu().numpy()                    # the one read-back: (R+G,) floats
+        n_pos_max = np.round(self.n_sample * self.pos_ratio)
+        fg = np.where(best >= self.pos_iou_thresh)[0]
+        n_fg = int(min(n_pos_max, fg.size))
+        if fg.size > 0:
+            fg = np.random.choice(fg, size=n_fg, replace=False)
+        bg = np.where((best < self.neg_iou_thresh_hi) & (best >= self.neg_iou_thresh_lo))[0]
+        n_bg = int(min(self.n_sample - n_fg, bg.size))
+        if bg.size > 0:
+            bg = np.random.choice(bg, size=n_bg, replace=False)
+        chosen = np.append(fg, bg).astype(np.int32)
+        chosen_d = upload(chosen, torch.int32, dev)
+        sample_roi, gt_roi_loc, gt_roi_label, gt_index = T.proposal_targets_gather(
+            cand, bbox_d, label_d, assigned_d, chosen_d, n_fg, loc_normalize_mean, loc_normalize_std)
+        job = dict(n=len(chosen), n_fg=n_fg, sample_roi=sample_roi, gt_index=gt_index)
+        return sample_roi, gt_roi_loc, gt_roi_label, job
+
+    def mask_targets_device(self, job, mask):
+        """14x14 mask targets on the device.  ``mask`` (G,H,W): a device tensor (uint8 / bool /
+        int32) stays on the device; a host array is uploaded as uint8."""
+        import torch
+        from ...functions import target_ops as T
+        dev = job['sample_roi'].device
+        if isinstance(mask, torch.Tensor):
+            m = mask.to(device=dev)
+            m = (m != 0).to(torch.uint8) if m.dtype != torch.uint8 else m
+        else:
+            m = torch.tensor(np.ascontiguousarray(np.asarray(mask) != 0).view(np.uint8), device=dev)
+        return T.mask_targets(m.contiguous(), job['sample_roi'], job['gt_index'], job['n_fg'],
+                              self.mask_size)
+
     def mask_targets(self, job, mask):
         """14x14 mask targets for the foreground RoIs; background rows stay -1 (:160-177).
         The reference one-hot encodes the {0,1} crop, resizes both channels with bilinear

@@ -347,6 +347,42 @@ int mrcnn_decode_cls_boxes(const float *roi, const float *cls_loc, int ld_loc,
                            const double *mean4, const double *std4, float size_h,
                            float size_w, void *stream);
 
+/* ---- Target creators: the device half ------------------------- */
+/* The deterministic arithmetic of ProposalTargetCreator.__call__
+ * (models/utils/proposal_target_creator.py:121-177) and chainercv's AnchorTargetCreator
+ * (call site models/mask_rcnn_train_chain.py:153-158): IoU matrices, label rules, regression
+ * targets, 14x14 mask targets.  The np.random draws stay with the caller (host), which reads
+ * max_iou / the anchor labels back, draws, and passes the chosen indices in. */
+/* chainercv bbox_iou(boxes_a (na,4), boxes_b (g,4)) reduced per row: max_iou (na), first
+ * argmax (na); optional full matrix iou (na,g) and its column maxima col_max (g). */
+int mrcnn_bbox_iou_argmax(const float *boxes_a, int na, const float *boxes_b, int g,
+                          float *iou, float *max_iou, int32_t *argmax, float *col_max,
+                          void *stream);
+/* AnchorTargetCreator label rule before subsampling: -1 / 0 (max < neg) / 1 (row holds a
+ * column maximum, or max >= pos). */
+int mrcnn_anchor_labels(const float *iou, const float *max_iou, const float *gt_max, int na,
+                        int g, float neg_iou_thresh, float pos_iou_thresh, int32_t *label,
+                        void *stream);
+/* label_inside[disabled[.]] = -1 (the host's draws), then the full-size targets: label (-1
+ * outside the image) and loc = bbox2loc(anchor, bbox[argmax]) (0 outside). */
+int mrcnn_anchor_targets_finish(const float *anchor_inside, const int32_t *inside_index,
+                                int32_t *label_inside, const int32_t *argmax, const float *bbox,
+                                int n_inside, const int32_t *disabled, int n_disabled,
+                                int n_anchor, float *loc, int32_t *label, void *stream);
+/* Rows chosen[0..n_sample) of the candidates (the first n_fg are foreground): sample_roi,
+ * gt_roi_loc = (bbox2loc(roi, bbox[assigned]) - mean) / std, gt_roi_label (class + 1 | 0),
+ * gt_index = assigned ground-truth box.  mean4 / std4 are HOST pointers to 4 floats. */
+int mrcnn_proposal_targets_gather(const float *cand, const float *bbox, const int32_t *gt_label,
+                                  const int32_t *assigned, const int32_t *chosen, int n_sample,
+                                  int n_fg, const float *mean4_host, const float *std4_host,
+                                  float *sample_roi, float *gt_roi_loc, int32_t *gt_roi_label,
+                                  int32_t *gt_index, void *stream);
+/* (n, M, M) int32 mask targets: rows < n_fg = crop of masks[gt_index] (uint8 (G,H,W)) at the
+ * rounded RoI, cv2 INTER_LINEAR to M x M, > 0.5; other rows -1. */
+int mrcnn_mask_targets(const uint8_t *masks, int G, int H, int W, const float *sample_roi,
+                       const int32_t *gt_index, int n, int n_fg, int M, int32_t *out,
+                       void *stream);
+
 /* ---- Gradient exchange over RCCL / xGMI ---------------------------------------------- */
 /* Replaces ChainerMN's communicator as the reference uses it
  * (examples/train_common.py:97-103 `chainermn.create_communicator('hierarchical')`, :178
