@@ -320,6 +320,8 @@ def main():
                          'over K pre-generated host batches with the image upload inside the '
                          'timed region (the reference converter uploads every iteration, '
                          'examples/train_common.py:219-225); 0 = skip')
+    ap.add_argument('--tune', default='',
+                    help='developer: comma-separated mrcnn_set_tuning knobs, e.g. small_m_split=4')
     ap.add_argument('--bucket-mb', type=float, default=16.0,
                     help='gradient all-reduce bucket size (data-parallel runs)')
     args = ap.parse_args()
@@ -346,6 +348,10 @@ def main():
     # only for tiny host-side tensor plumbing) from oversubscribing the cores
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(1, 2 * world))))
     _lib.load()                                   # fail loudly without the HIP library
+    for kv in args.tune.split(','):
+        if '=' in kv:
+            k, v = kv.split('=')
+            _lib.check(_lib.load().mrcnn_set_tuning(k.encode(), int(v)), 'set_tuning')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device; there is no CPU path')
     torch.cuda.set_device(local)

@@ -968,18 +968,21 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, i
 // Workgroups resident at once: 128x128 tiles run 2 per CU (73 KB LDS), 64x64 tiles 4 per CU.
 constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
 
+int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM launch (lowers
+                       // the resident workgroups per CU for co-residency experiments)
+
 template <int TM, int TN, int MODE, bool MASKED>
 void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t s)
 {
     if constexpr (MODE == WGRAD && !MASKED) {
         if (p.perm_n > 0) {
             hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
-                               dim3((unsigned)tiles, splits), dim3(256), 0, s, p);
+                               dim3((unsigned)tiles, splits), dim3(256), g_extra_lds, s, p);
             return;
         }
     }
     hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED>), dim3((unsigned)tiles, splits),
-                       dim3(256), 0, s, p);
+                       dim3(256), g_extra_lds, s, p);
 }
 
 inline bool is_masked(const GemmParams &p) { return p.mask_y != nullptr || p.in_scale != nullptr; }
@@ -1017,7 +1020,7 @@ void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
 // multiples of 256 tiles run as usual; the leftover rows (< 154 tiles) are cut along K into
 // `splits` short workgroups that spread over all CUs, write raw partial sums into slabs, and
 // a small kernel sums the slabs in order and applies the epilogue (deterministic).
-constexpr int64_t kSplitWsBytes = 154ll * 64 * 64 * 16 * 4;
+constexpr int64_t kSplitWsBytes = 192ll << 20;   // >= 154 leftover tiles x 16 slabs; whole small-M outputs x splits
 
 struct FixParams {
     const float *ws;
@@ -1114,12 +1117,29 @@ void launch_remainder(const GemmParams &p, int rows_lo, hipStream_t s)
     launch_split_rows<MODE>(p, rows_lo, (int)splits, total_slices, s);
 }
 
+int g_small_m_split = 0;          // mrcnn_set_tuning("small_m_split", target workgroups per CU)
+
 template <int MODE>
 void launch_small(const GemmParams &p, hipStream_t s)
 {
     const int64_t tm = mrcnn::ceil_div(p.M, 64), tn = mrcnn::ceil_div(p.N, 64);
     const int64_t T = tm * tn, whole = (T / 256) * 256, rem = T - whole;
     const int total_slices = p.R * p.S * (int)mrcnn::ceil_div(p.Kc, BK);
+    // Occupancy-driven split-K: a wave of the 64x64 kernel spends only about a quarter of a K
+    // slice issuing MFMAs, so a SIMD needs ~4 co-resident waves to keep its matrix pipe busy.
+    // A small-M problem has only T / 256 workgroups per CU; cutting every tile along K into
+    // `splits` slabs multiplies the resident waves (each at least 8 slices deep) at the price
+    // of the ordered slab sum.
+    if (g_small_m_split > 0 && can_split_rows<MODE>(p) && T < 256ll * g_small_m_split &&
+        total_slices >= 16) {
+        int64_t splits = std::min<int64_t>(std::min<int64_t>(16, total_slices / 8),
+                                           mrcnn::ceil_div(256ll * g_small_m_split, T));
+        while (splits > 1 && (int64_t)p.M * p.N * splits * 4 > kSplitWsBytes) --splits;
+        if (splits >= 2) {
+            launch_split_rows<MODE>(p, 0, (int)splits, total_slices, s);
+            return;
+        }
+    }
     const bool can_split = can_split_rows<MODE>(p) && whole > 0 && whole <= 1024 && rem > 0 &&
                            rem < 154 && total_slices >= 8;   // beyond 4 tile-times per CU the
                                                              // two extra launches cost more than
@@ -1247,6 +1267,14 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     MRCNN_REQUIRE(name != nullptr, "set_tuning: null name");
     if (strcmp(name, "position_major_rows") == 0) {
         g_position_major_rows = value != 0;
+        return 0;
+    }
+    if (strcmp(name, "gemm_extra_lds") == 0) {
+        g_extra_lds = value;
+        return 0;
+    }
+    if (strcmp(name, "small_m_split") == 0) {
+        g_small_m_split = value;
         return 0;
     }
     MRCNN_REQUIRE(false, "set_tuning: unknown option '%s'", name);

@@ -46,6 +46,10 @@ def timeit(fn, iters=10):
 def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None
     lib = _lib.load()
+    for kv in os.environ.get('BENCH_TUNE', '').split(','):
+        if '=' in kv:
+            k, v = kv.split('=')
+            _lib.check(lib.mrcnn_set_tuning(k.encode(), int(v)), 'set_tuning')
     tot = {'fwd': 0., 'dgrad': 0., 'wgrad': 0.}
     print('%-28s %11s %11s %11s %11s  (TFLOP/s | ms)' % ('shape', 'fwd', 'dgrad', 'wgrad', 'dgrad_wt'))
     for name, N, C, H, W, K, k, s, p in SHAPES:
