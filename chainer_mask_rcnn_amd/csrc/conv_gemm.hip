@@ -224,17 +224,11 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
 // Removed; see the history of this file.)
 // WPERM: WGRAD with position-major pixel order (GemmParams::perm_n) — a separate instantiation
 // because the natural-order kernel sits exactly at its 168-register budget.
-// VALU: the same tile computed on the VECTOR ALU (v_fma_f32, 8x8 register micro-tile per lane)
-// instead of the matrix pipe.  gfx950's fp32 MFMA and fp32 VALU have the same peak and are
-// separate pipes (MI355X_MICROARCH.md, "Wave scheduling"): a launch of this variant over a
-// slice of the rows, queued on a second stream, runs BESIDE the MFMA launch on the same CUs.
-template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool VALU = false>
-__global__ void __launch_bounds__(256, VALU ? 3 : min_blocks(TM, MODE, MASKED))
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false>
+__global__ void __launch_bounds__(256, min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
-    static_assert(!VALU || (MODE == FWD && TM == 2 && TN == 2 && !MASKED && MRCNN_GEMM_WIDE_EPILOGUE != 0),
-                  "VALU is a variant of the forward-form 128x128 kernel");
     constexpr bool SINGLEBUF = single_buffered(TM, MODE, MASKED);
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
@@ -541,21 +535,13 @@ conv_gemm_kernel(const GemmParams p)
         }
     };
 
-    f32x16 acc[VALU ? 1 : TM][VALU ? 1 : TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < (VALU ? 1 : TM); ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < (VALU ? 1 : TN); ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // VALU variant: lane (vy, vx) of the wave's 64x64 quadrant owns rows vy + 8j, cols vx + 8j'
-    // (interleaved, so that the b128 LDS reads of 8 lanes hit 8 disjoint bank windows)
-    float vacc[VALU ? 8 : 1][VALU ? 8 : 1];
-#pragma unroll
-    for (int i = 0; i < (VALU ? 8 : 1); ++i)
-#pragma unroll
-        for (int j = 0; j < (VALU ? 8 : 1); ++j) vacc[i][j] = 0.f;
-    const int vy = lane & 7, vx = lane >> 3;
 
     const int li = lane & 31, lk = lane >> 5;
 
@@ -592,29 +578,6 @@ conv_gemm_kernel(const GemmParams p)
     auto compute = [&](int buf) {
         const float *sa = smem[buf];
         const float *sb = smem[buf] + C_::A_FLOATS;
-        if constexpr (VALU) {
-            const float *pa = sa + (wm * 64 + vy) * (BK + KPAD);
-            const float *pb = sb + (wn * 64 + vx) * (BK + KPAD);
-#pragma unroll 1
-            for (int kc = 0; kc < BK / 2; ++kc) {
-                float2 a2[8], b2[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    a2[j] = *reinterpret_cast<const float2 *>(pa + 8 * j * (BK + KPAD) + kc * 2);
-                    b2[j] = *reinterpret_cast<const float2 *>(pb + 8 * j * (BK + KPAD) + kc * 2);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float v = vacc[i][j];
-                        v = fmaf(a2[i].x, b2[j].x, v);
-                        v = fmaf(a2[i].y, b2[j].y, v);
-                        vacc[i][j] = v;
-                    }
-            }
-            return;
-        }
         float af[2][TM][4], bf[2][TN][4];
         load_frag(sa, sb, 0, af[0], bf[0]);
         if (SETPRIO) __builtin_amdgcn_s_setprio(1);
@@ -744,20 +707,11 @@ conv_gemm_kernel(const GemmParams p)
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if constexpr (VALU) {
-                // rows 32 i .. 32 i + 31 of the quadrant = micro-tile rows j = 4 i .. 4 i + 3
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        ep[(vy + 8 * jj) * LDW + vx + 8 * c] = vacc[4 * i + jj][c];
-            } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     ep[((e & 3) + 8 * (e >> 2) + 4 * lk) * LDW + j * 32 + li] = acc[i][j][e];
-            }
             // same wave writes and reads: LDS operations of a wave execute in order
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1016,7 +970,6 @@ constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
 
 int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM launch (lowers
                        // the resident workgroups per CU for co-residency experiments)
-int g_launch_extra_lds = 0;   // set around one launch by the hybrid MFMA + VALU policy
 
 template <int TM, int TN, int MODE, bool MASKED>
 void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t s)
@@ -1029,7 +982,7 @@ void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t
         }
     }
     hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED>), dim3((unsigned)tiles, splits),
-                       dim3(256), g_extra_lds + g_launch_extra_lds, s, p);
+                       dim3(256), g_extra_lds, s, p);
 }
 
 inline bool is_masked(const GemmParams &p) { return p.mask_y != nullptr || p.in_scale != nullptr; }
@@ -1205,54 +1158,6 @@ void launch_small(const GemmParams &p, hipStream_t s)
     launch_split_rows<MODE>(p, rows_main, splits, total_slices, s);
 }
 
-// ---- hybrid launch: matrix pipe + vector ALU side by side --------------------------------
-// The last `g_valu_pct` percent of the rows of a large forward-form launch are computed by the
-// VALU variant of the kernel on a second stream while the MFMA launch handles the rest: the two
-// pipes are separate, so both kernels make progress on the same CUs.  The MFMA launch is held
-// to two workgroups per CU (dynamic LDS) so that one VALU workgroup (4 waves, one per SIMD)
-// finds registers and LDS on every CU.
-int g_valu_pct = 0;               // mrcnn_set_tuning("valu_rows_pct", 0..50)
-constexpr int kHybridExtraLds = 17 << 10;
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-SideStream g_side[16];
-SideStream *side_stream()
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideStream &ss = g_side[dev];
-    if (!ss.s) {
-        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        (void)hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&ss.join, hipEventDisableTiming);
-    }
-    return &ss;
-}
-
-void launch_tiles_hybrid(const GemmParams &p, int rows_main, hipStream_t s)
-{
-    const int64_t tn = mrcnn::ceil_div(p.N, 128);
-    const int64_t tm = rows_main / 128;
-    int64_t tm_v = tm * g_valu_pct / 100;
-    SideStream *ss = tm_v > 0 && tm * tn >= 768 ? side_stream() : nullptr;
-    if (!ss) {
-        launch_tiles<2, 2, FWD>(p, 0, rows_main, 1, s);
-        return;
-    }
-    const int rows_m = (int)((tm - tm_v) * 128);
-    (void)hipEventRecord(ss->fork, s);
-    (void)hipStreamWaitEvent(ss->s, ss->fork, 0);
-    GemmParams q = p;
-    q.m_lo = rows_m;
-    q.M = rows_main;
-    hipLaunchKernelGGL((conv_gemm_kernel<2, 2, FWD, false, false, true>),
-                       dim3((unsigned)(tm_v * tn), 1), dim3(256), 0, ss->s, q);
-    (void)hipEventRecord(ss->join, ss->s);
-    g_launch_extra_lds = kHybridExtraLds;
-    if (rows_m > 0) launch_tiles<2, 2, FWD>(p, 0, rows_m, 1, s);
-    g_launch_extra_lds = 0;
-    (void)hipStreamWaitEvent(s, ss->join, 0);
-}
-
 // FWD / DGRAD launch policy.  With T 128x128 tiles and 512 resident workgroups a launch
 // takes ceil(T/512) "rounds"; when the last round would be mostly empty (e.g. T = 536 or
 // 1568) the rows of the full rounds run as 128x128 tiles and the leftover rows as a second,
@@ -1278,14 +1183,7 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
             }
         }
         const int rows_main = (int)std::min<int64_t>(p.M, main_tiles_m * 128);
-        if constexpr (MODE == FWD) {
-            if (g_valu_pct > 0 && !is_masked(p) && splits == 1 && !p.stem && rows_main % 128 == 0)
-                launch_tiles_hybrid(p, rows_main, s);
-            else
-                launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
-        } else {
-            launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
-        }
+        launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
         if (rows_main < p.M) launch_remainder<MODE>(p, rows_main, s);
     }
     return mrcnn::check_launch("conv_gemm");
@@ -1369,10 +1267,6 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     MRCNN_REQUIRE(name != nullptr, "set_tuning: null name");
     if (strcmp(name, "position_major_rows") == 0) {
         g_position_major_rows = value != 0;
-        return 0;
-    }
-    if (strcmp(name, "valu_rows_pct") == 0) {
-        g_valu_pct = value < 0 ? 0 : (value > 100 ? 100 : value);
         return 0;
     }
     if (strcmp(name, "gemm_extra_lds") == 0) {

@@ -1,5 +1,10 @@
-"""Developer experiment: the hybrid MFMA + VALU launch (mrcnn_set_tuning valu_rows_pct) —
-same values as the pure MFMA launch (to fp32 rounding) and timing per row share."""
+"""Developer experiment (historical): the hybrid MFMA + VALU launch — the last `valu_rows_pct`
+percent of a big forward-form launch's rows computed by a vector-ALU variant of the GEMM kernel
+on a second stream, beside the MFMA launch.  Result (profiles/r02_exp_hybrid_valu_mfma*.{log,txt}):
+values identical to fp32 rounding, the VALU-only variant reaches 86 TFLOP/s, but co-resident the
+two are zero-sum (MFMA 112 + VALU 18 = the 130 TFLOP/s of the MFMA kernel alone).  The variant
+was removed from csrc/conv_gemm.hip again; it lives in the commit "Experiment: VALU variant of
+the 128x128 GEMM beside the MFMA launch".  This script needs that commit's library."""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
