@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmrcnn_hip.so')
+LIB_PATH = os.environ.get('MRCNN_HIP_LIB') or os.path.join(_HERE, 'libmrcnn_hip.so')   # override: developer A/B builds
 
 EPI_BIAS, EPI_AFFINE, EPI_RESIDUAL, EPI_RELU, EPI_ACCUM = 1, 2, 4, 8, 16
 
