@@ -11,3 +11,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_sta
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -o ${TAG} -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -o ${TAG} -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_write.log 2>&1
 ls $R/gpurun_out | grep ${TAG}
+python $R/bench.py --force-dp --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_dp1.json 2>> $R/gpurun_out/${TAG}_bench.err
+python $R/bench.py --layers 101 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_r101.json 2>> $R/gpurun_out/${TAG}_bench.err

@@ -6,7 +6,7 @@ g, p = os.path.join(root, 'gpurun_out'), os.path.join(root, 'profiles')
 os.makedirs(p, exist_ok=True)
 shutil.copy(os.path.join(g, '%s_stats' % tag, '%s_kernel_stats.csv' % tag),
             os.path.join(p, '%s_kernel_stats.csv' % tag))
-for name in ('bench', 'bench_allkinds', 'bench_infer'):
+for name in ('bench', 'bench_allkinds', 'bench_infer', 'bench_dp1', 'bench_r101'):
     src = os.path.join(g, '%s_%s.json' % (tag, name))
     if os.path.exists(src):
         lines = [l for l in open(src).read().splitlines() if l.startswith('{')]
