@@ -140,7 +140,10 @@ class MaskRCNN(torch.nn.Module):
 
         if self._detections_per_im > 0:
             # literal restatement of models/mask_rcnn.py:255-260 (an argsort
-            # permutation compared with a rank threshold)
+            # permutation compared with a rank threshold).  The reference
+            # calls np.argsort with its default (unstable) kind, so the order of EQUAL scores —
+            # and with it which of two tied detections survives the cut — is unspecified there;
+            # the stable kind used here is one of the orders it can produce.
             indices = np.argsort(score, kind='stable')
             ok = indices >= (len(indices) - self._detections_per_im)
             bbox, label, score = bbox[ok], label[ok], score[ok]

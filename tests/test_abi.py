@@ -93,3 +93,16 @@ def test_roi_align_argument_errors():
         functions.roi_align_2d(torch.zeros(1, 1, 2, 2), torch.zeros(1, 5), 2, 2, 1.0, axes='zz')
     with pytest.raises(TypeError):
         functions.ROIAlign2D(2, 2, 1.0)(torch.zeros(1, 1, 2, 2), torch.zeros(1, 4))
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` self-launches one rank per GPU (SCALE runs); with fewer than
+    N devices visible it must fail loudly BEFORE any rendezvous, not hang or oversubscribe."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert 'ROCm device(s) visible' in r.stderr and r.stdout.strip() == ''
