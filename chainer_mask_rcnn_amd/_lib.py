@@ -50,6 +50,7 @@ SIGNATURES = {
     'mrcnn_topk_desc_batched': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'mrcnn_detect_sort_workspace_bytes': (c_i64, [c_int, c_int]),
     'mrcnn_detect_sort': (c_int, [c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'mrcnn_detect_compact': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'mrcnn_gather_rows': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'mrcnn_nms_workspace_bytes': (c_i64, [c_int, c_int]),
     'mrcnn_nms_sorted': (c_int, [c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_vp, c_vp, c_vp]),

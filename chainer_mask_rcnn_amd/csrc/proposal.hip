@@ -351,6 +351,60 @@ extern "C" int mrcnn_detect_sort(const float *prob, const float *cls_bbox, int R
     return mrcnn::check_launch("detect_sort");
 }
 
+namespace {
+// Second half of MaskRCNN._suppress (models/mask_rcnn.py:195-202) on the device: the kept rows
+// of every class, class after class (ascending label) and in NMS keep order inside a class,
+// packed into dense arrays.  One workgroup: a serial prefix sum over the <= 1024 classes in
+// LDS, then the rows are copied cooperatively.
+__global__ void __launch_bounds__(256)
+detect_compact_kernel(const int32_t *__restrict__ keep, const int32_t *__restrict__ n_keep,
+                      const float4 *__restrict__ sorted_boxes, const float *__restrict__ sorted_prob,
+                      int G, int R, float4 *__restrict__ bbox, int32_t *__restrict__ label,
+                      float *__restrict__ score, int32_t *__restrict__ total)
+{
+    extern __shared__ int32_t offs[];             // G + 1 offsets
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int l = 0; l < G; ++l) { offs[l] = acc; acc += min(max(n_keep[l], 0), R); }
+        offs[G] = acc;
+        *total = acc;
+    }
+    __syncthreads();
+    for (int l = 0; l < G; ++l) {
+        const int n = offs[l + 1] - offs[l];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int k = keep[(int64_t)l * R + i];
+            const int o = offs[l] + i;
+            bbox[o] = sorted_boxes[(int64_t)l * R + k];
+            score[o] = sorted_prob[(int64_t)l * R + k];
+            label[o] = l;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mrcnn_detect_compact(const int32_t *keep, const int32_t *n_keep,
+                                    const float *sorted_boxes, const float *sorted_prob, int G,
+                                    int R, float *bbox, int32_t *label, float *score,
+                                    int32_t *total, void *stream)
+{
+    MRCNN_REQUIRE(G > 0 && G <= 4096 && R >= 0, "detect_compact: bad shape");
+    MRCNN_REQUIRE(total, "detect_compact: null total");
+    hipStream_t s = mrcnn::as_stream(stream);
+    if (R == 0) {
+        MRCNN_HIP_TRY(hipMemsetAsync(total, 0, 4, s));
+        return 0;
+    }
+    MRCNN_REQUIRE(keep && n_keep && sorted_boxes && sorted_prob && bbox && label && score,
+                  "detect_compact: null pointer");
+    MRCNN_REQUIRE(((uintptr_t)sorted_boxes | (uintptr_t)bbox) % 16 == 0,
+                  "detect_compact: boxes must be 16-byte aligned");
+    hipLaunchKernelGGL(detect_compact_kernel, dim3(1), dim3(256), (size_t)(G + 1) * 4, s, keep, n_keep,
+                       (const float4 *)sorted_boxes, sorted_prob, G, R, (float4 *)bbox, label, score,
+                       total);
+    return mrcnn::check_launch("detect_compact");
+}
+
 extern "C" int mrcnn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev,
                                  int n_max, int cols, float *dst, void *stream)
 {

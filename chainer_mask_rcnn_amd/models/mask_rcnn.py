@@ -68,23 +68,26 @@ class MaskRCNN(torch.nn.Module):
                   R, self.n_class, float(self.score_thresh), _lib.ptr(sorted_boxes),
                   _lib.ptr(sorted_prob), _lib.ptr(counts), _lib.ptr(ws), _lib.stream_ptr())
         keep, n_keep = P.nms_sorted_batched(sorted_boxes, counts, self.nms_thresh)
-        return keep, n_keep, sorted_boxes, sorted_prob
+        # pack the kept rows of all classes on the device: the host then reads one count and
+        # D rows instead of four (n_fg, R) arrays
+        cap = n_fg * max(R, 1)
+        bbox = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+        label = torch.empty((cap,), dtype=torch.int32, device=dev)
+        score = torch.empty((cap,), dtype=torch.float32, device=dev)
+        total = torch.empty((1,), dtype=torch.int32, device=dev)
+        _lib.call('mrcnn_detect_compact', _lib.ptr(keep), _lib.ptr(n_keep), _lib.ptr(sorted_boxes),
+                  _lib.ptr(sorted_prob), n_fg, max(R, 1) if R else 0, _lib.ptr(bbox), _lib.ptr(label),
+                  _lib.ptr(score), _lib.ptr(total), _lib.stream_ptr())
+        return bbox, label, score, total
 
     @staticmethod
-    def _suppress_finish(keep, n_keep, sorted_boxes, sorted_prob):
-        """Host half: gather the kept rows class by class.  Returns host arrays bbox (D,4)
-        f32, label (D,) i32, score (D,) f32 ordered by class then by score."""
-        keep, n_keep = keep.cpu().numpy(), n_keep.cpu().numpy()
-        sorted_boxes, sorted_prob = sorted_boxes.cpu().numpy(), sorted_prob.cpu().numpy()
-        bbox, label, score = [], [], []
-        for l in range(len(n_keep)):
-            k = keep[l, :n_keep[l]]
-            bbox.append(sorted_boxes[l, k])
-            label.append(np.full((len(k),), l, dtype=np.int32))
-            score.append(sorted_prob[l, k])
-        return (np.concatenate(bbox, 0).astype(np.float32),
-                np.concatenate(label, 0).astype(np.int32),
-                np.concatenate(score, 0).astype(np.float32))
+    def _suppress_finish(bbox, label, score, total):
+        """Host half: read the packed rows back.  Returns host arrays bbox (D,4) f32, label (D,)
+        i32, score (D,) f32 ordered by class then by score."""
+        d = int(total.item())
+        return (bbox[:d].cpu().numpy().astype(np.float32, copy=False),
+                label[:d].cpu().numpy().astype(np.int32, copy=False),
+                score[:d].cpu().numpy().astype(np.float32, copy=False))
 
     def _suppress(self, cls_bbox, prob):
         return self._suppress_finish(*self._suppress_queue(cls_bbox, prob))
@@ -99,8 +102,11 @@ class MaskRCNN(torch.nn.Module):
             scores.append(score)
         return bboxes, labels, scores
 
-    def _queue_detections(self, roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales):
-        """Device half of ``_to_bboxes`` for every image, queued without synchronising."""
+    def _queue_detections(self, roi_cls_locs, roi_scores, rois, roi_indices, sizes, scales,
+                          bounds=None):
+        """Device half of ``_to_bboxes`` for every image, queued without synchronising
+        (``bounds``: the per-image row bounds of ``rois`` if the caller already knows them —
+        reading ``roi_indices`` back would wait for everything queued so far)."""
         probs = F.softmax(roi_scores.detach())
         roi_cls_locs = roi_cls_locs.detach()
         if roi_cls_locs.stride(1) != 1:
@@ -111,8 +117,9 @@ class MaskRCNN(torch.nn.Module):
         # RoIs are grouped by image, in order (RegionProposalNetwork): one host read gives the
         # slice bounds.  The device work of every image is queued first; the host halves run
         # afterwards while later images' kernels are still executing.
-        counts = np.bincount(roi_indices.cpu().numpy().astype(np.int64), minlength=len(sizes))
-        bounds = np.concatenate([[0], np.cumsum(counts)])
+        if bounds is None:
+            counts = np.bincount(roi_indices.cpu().numpy().astype(np.int64), minlength=len(sizes))
+            bounds = np.concatenate([[0], np.cumsum(counts)])
         queued = []
         for index in range(len(sizes)):
             lo, hi = int(bounds[index]), int(bounds[index + 1])
@@ -272,7 +279,9 @@ class MaskRCNN(torch.nn.Module):
                 # (rois are grouped by image in order: one host read of the index column gives
                 # the slice bounds; a boolean mask per image would synchronise eight times and
                 # leave the GPU idle while the host queues the next head)
-                counts = np.bincount(roi_indices.cpu().numpy(), minlength=x.shape[0])
+                counts = getattr(self.rpn, 'last_counts', None)   # host ints of THIS rpn call
+                if counts is None or len(counts) != x.shape[0]:
+                    counts = np.bincount(roi_indices.cpu().numpy(), minlength=x.shape[0])
                 bounds = np.concatenate([[0], np.cumsum(counts)])
                 locs, scs = [], []
                 for i in range(x.shape[0]):
@@ -286,8 +295,10 @@ class MaskRCNN(torch.nn.Module):
             # group by group and each group's mask-head pass is launched as soon as its
             # boxes are final, so the GPU computes masks while the host finishes the next
             # group (rows of the head are independent: same values as one pass over all).
+            # (the row bounds are already on the host: the detection kernels queue up right
+            # behind the heads instead of after a read-back that drains the GPU)
             queued = self._queue_detections(roi_cls_locs, roi_scores, rois, roi_indices,
-                                            sizes, scales)
+                                            sizes, scales, bounds=bounds)
             n_img = len(queued)
             n_groups = 2 if n_img >= 4 else 1
             per = -(-n_img // n_groups)
@@ -301,7 +312,13 @@ class MaskRCNN(torch.nn.Module):
                     scores.append(s)
                 roi_masks += self._roi_masks_group(h, [bboxes[i] for i in ids], ids, scales)
             if masks_to_host:
-                roi_masks = [m.cpu().numpy() for m in roi_masks]
+                # (N x <=100 x 80 x 14 x 14 floats: ~50 MB for a batch of 8) through pinned
+                # host memory, all copies queued before the one synchronisation
+                host = [torch.empty(m.shape, dtype=m.dtype, pin_memory=True) for m in roi_masks]
+                for h_, m in zip(host, roi_masks):
+                    h_.copy_(m, non_blocking=True)
+                torch.cuda.current_stream(x.device).synchronize()
+                roi_masks = [h_.numpy() for h_ in host]
         finally:
             self.train(was_training)
         if return_intermediates:

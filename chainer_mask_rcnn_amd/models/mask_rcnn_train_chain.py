@@ -267,8 +267,7 @@ class MaskRCNNTrainChain(torch.nn.Module):
         rpn_locs, rpn_scores, rois, roi_indices, anchor = self.mask_rcnn.rpn(
             features, img_size, scales)
         mark('extractor+rpn queued')
-        pc = getattr(self.mask_rcnn.rpn, 'proposal_layer', None)
-        counts = getattr(pc, 'last_counts', None)
+        counts = getattr(self.mask_rcnn.rpn, 'last_counts', None)
         if counts is None:
             counts = np.bincount(roi_indices.cpu().numpy(), minlength=batch_size).tolist()
         bounds = np.concatenate([[0], np.cumsum(counts)]).astype(int)

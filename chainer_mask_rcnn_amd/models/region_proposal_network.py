@@ -76,6 +76,7 @@ class RegionProposalNetwork(torch.nn.Module):
         else:
             rois = [self.proposal_layer(rpn_locs[i], rpn_scores[i], anchor, img_size,
                                         scale=float(scales[i])) for i in range(n)]
+        self.last_counts = [int(len(roi)) for roi in rois]     # host-known: no read-back
         roi_indices = [torch.full((len(roi),), i, dtype=torch.int32, device=x.device)
                        for i, roi in enumerate(rois)]
         rois = torch.cat(rois, dim=0)

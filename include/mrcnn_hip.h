@@ -336,6 +336,13 @@ int mrcnn_prepare_image(const void *src_chw, int src_is_u8, int C, int H, int W,
 int mrcnn_paste_masks(const float *mask_logits, const int32_t *label, const float *bbox,
                       int D, int M, int Kc, int im_h, int im_w, uint8_t *out, void *stream);
 
+/* Second half of MaskRCNN._suppress (models/mask_rcnn.py:195-202): the rows kept by
+ * mrcnn_nms_sorted_batched (keep (G,R), n_keep (G)) of every class packed densely, class after
+ * class and in keep order: bbox (<= G*R, 4), label, score, *total = number of rows. */
+int mrcnn_detect_compact(const int32_t *keep, const int32_t *n_keep, const float *sorted_boxes,
+                         const float *sorted_prob, int G, int R, float *bbox, int32_t *label,
+                         float *score, int32_t *total, void *stream);
+
 /* ---- Inference post-processing (models/mask_rcnn.py:204-265) ---------------- */
 /* Per-class decode: cls_bbox[r,l,:] = clip(loc2bbox(roi[r]/scale,
  * cls_loc[r,l,:]*std+mean), 0, size) for all classes (:225-240). */
