@@ -178,7 +178,6 @@ struct Cfg {
 // and drops stores.  No per-element branch or select touches a loaded value, so every load
 // of a K slice stays in flight across the slice's MFMAs.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
 constexpr unsigned kOOB = 0x80000000u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
@@ -225,38 +224,20 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
 // Removed; see the history of this file.)
 // WPERM: WGRAD with position-major pixel order (GemmParams::perm_n) — a separate instantiation
 // because the natural-order kernel sits exactly at its 168-register budget.
-// DMA: the K slices of the forward-form 128x128 kernel go global -> LDS directly
-// (`buffer_load_dwordx4 ... lds`, 1 KiB = 16 rows x 64 B per wave instruction): no staging
-// VGPRs and no ds_write pass, so the kernel fits 128 registers and FOUR workgroups per CU.
-// The LDS image of a wave instruction is lane-linear, so rows are unpadded (128 B) and bank
-// conflicts are avoided by an XOR swizzle applied to BOTH sides: lane l of an instruction loads
-// the 16-byte chunk (l % 4) ^ ((row >> 2) & 3) of its 64-byte row, and the fragment reads fetch
-// chunk c of row r from slot c ^ ((r >> 2) & 3).  Out-of-range lanes (padding taps, tile tails)
-// write zeros (probed: tools/exp/dma_probe.py).
-template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool DMA = false>
-__global__ void __launch_bounds__(256, DMA ? 4 : min_blocks(TM, MODE, MASKED))
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false>
+__global__ void __launch_bounds__(256, min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
-    static_assert(!DMA || (MODE == FWD && TM == 2 && TN == 2 && !MASKED &&
-                           MRCNN_GEMM_WIDE_EPILOGUE != 0),
-                  "DMA is a variant of the forward-form 128x128 kernel");
-    constexpr bool SINGLEBUF = DMA || single_buffered(TM, MODE, MASKED);
+    constexpr bool SINGLEBUF = single_buffered(TM, MODE, MASKED);
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
-    // K depth of one slice: the DMA variant runs TWO 16-deep stages in the LDS one 32-deep
-    // stage takes (a slice is issued one compute phase ahead: one barrier per slice)
-    constexpr int KB = DMA ? 16 : BK;
-    constexpr int AV = DMA ? BM * KB / 4 / 256 : C_::A_V4, BV = DMA ? BN * KB / 4 / 256 : C_::B_V4;
+    constexpr int AV = C_::A_V4, BV = C_::B_V4;
     constexpr bool HAS_MASK = MASKED;
     constexpr bool FWDLIKE = is_fwd(MODE);
-    // DMA: unpadded rows (2 x 128 x 32 floats); the epilogue's transpose scratch (4 waves x 32
-    // rows x 68 floats) is the larger of the two uses
-    constexpr int STAGE_FLOATS = DMA ? 4 * 32 * (32 * TN + 4) : C_::A_FLOATS + C_::B_FLOATS;
-    constexpr int DMA_A_FLOATS = BM * KB, DMA_STAGE = (BM + BN) * KB;
-    __shared__ __attribute__((aligned(16))) float smem_all[1][SINGLEBUF ? 1 : 2][STAGE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem_all[1][SINGLEBUF ? 1 : 2][C_::A_FLOATS + C_::B_FLOATS];
 
-    float (*smem)[STAGE_FLOATS] = smem_all[0];
+    float (*smem)[C_::A_FLOATS + C_::B_FLOATS] = smem_all[0];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -284,10 +265,8 @@ conv_gemm_kernel(const GemmParams p)
     const int n0 = (tile % ntn) * BN;
 
     // ---------------- per-thread gather state -----------------------------------
-    constexpr int KC_C4 = KB / 4, KC_RPP = 256 / KC_C4;   // float4 per row, rows per pass
-    const int kc_row = tid / KC_C4;
-    // DMA: the lane's LDS slot is (tid % 8); the global chunk it fetches is XOR-swizzled
-    const int kc_c4 = DMA ? ((tid % KC_C4) ^ ((kc_row >> 2) & 3)) : tid % KC_C4;
+    constexpr int KC_C4 = BK / 4, KC_RPP = 256 / KC_C4;   // float4 per row, rows per pass
+    const int kc_row = tid / KC_C4, kc_c4 = tid % KC_C4;
     int a_n[AV], a_y[AV], a_x[AV];     // FWD/DGRAD: pixel coords of each A row
     if (MODE != WGRAD) {
 #pragma unroll
@@ -360,7 +339,7 @@ conv_gemm_kernel(const GemmParams p)
     }
 
     const int adv_x = BK % p.gq, adv_y = (BK / p.gq) % p.gp, adv_n = BK / (p.gp * p.gq);
-    const int cprs = (MODE == WGRAD) ? 1 : (p.Kc + KB - 1) / KB;  // K slices per (r,s)
+    const int cprs = (MODE == WGRAD) ? 1 : (p.Kc + BK - 1) / BK;  // K slices per (r,s)
     // FWD/DGRAD split-K (leftover rows of a small-M problem, see launch()): this workgroup
     // runs slices [kt0, kt0 + nslices) and writes raw partial sums into its slab
     // position-major rows: the taps that are inside the map for at least one position of this
@@ -435,7 +414,6 @@ conv_gemm_kernel(const GemmParams p)
     // FWD/DGRAD K order: channel chunk outer, filter tap (r,s) inner — consecutive slices re-read
     // the same 32-channel slab of neighbouring pixels, which stays in the CU's L1.
     auto load_slice = [&](int kt) {
-        [[maybe_unused]] float *dma_stage = &smem_all[0][0][0] + (DMA ? (kt & 1) * DMA_STAGE : 0);
         if (FWDLIKE || MODE == DGRAD) {
             kt += kt0;
             int chunk, rs;
@@ -446,7 +424,7 @@ conv_gemm_kernel(const GemmParams p)
                 chunk = kt / RS;
                 rs = kt - chunk * RS;
             }
-            const int c0 = chunk * KB;
+            const int c0 = chunk * BK;
             const int r = rs / p.S, s = rs - r * p.S;
             const int cc = c0 + kc_c4 * 4;
             const bool c_ok = p.stem || cc < p.Kc;
@@ -459,12 +437,7 @@ conv_gemm_kernel(const GemmParams p)
                 else { iy = a_y[i] - r; ix = a_x[i] - s; }
                 const bool ok = c_ok && (unsigned)iy < (unsigned)p.sh && (unsigned)ix < (unsigned)p.sw;
                 const unsigned off = ok ? 4u * (a_base[i] + (unsigned)tap) : kOOB;
-                if constexpr (DMA) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        rA, (lds_ptr_t)(dma_stage + ((64 / KC_C4) * wave + KC_RPP * i) * KB), 16, off, 0, 0, 0);
-                } else {
-                    ra[i] = bload4(rA, off);
-                }
+                ra[i] = bload4(rA, off);
                 if (HAS_MASK && use_mask) rm[i] = bload4(rMask, off);
             }
             if (HAS_MASK && use_scale)
@@ -473,16 +446,8 @@ conv_gemm_kernel(const GemmParams p)
             if (FWDLIKE) {
                 const unsigned wofs = (unsigned)(rs * p.Kc + c0);
 #pragma unroll
-                for (int i = 0; i < BV; ++i) {
-                    const unsigned off = cc < p.Kc ? 4u * (b_base[i] + wofs) : kOOB;
-                    if constexpr (DMA) {
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            rB, (lds_ptr_t)(dma_stage + DMA_A_FLOATS + ((64 / KC_C4) * wave + KC_RPP * i) * KB),
-                            16, off, 0, 0, 0);
-                    } else {
-                        rb[i] = bload4(rB, off);
-                    }
-                }
+                for (int i = 0; i < BV; ++i)
+                    rb[i] = bload4(rB, cc < p.Kc ? 4u * (b_base[i] + wofs) : kOOB);
             } else {
                 const unsigned wofs = (unsigned)(c0 * p.ldb + rs * p.cin);
 #pragma unroll
@@ -547,7 +512,6 @@ conv_gemm_kernel(const GemmParams p)
 
     // registers -> LDS; the fused epilogue-backward (ReLU mask, affine scale) is applied here
     auto store_slice = [&](int buf) {
-        if constexpr (DMA) return;
         float *sa = smem[buf];
         float *sb = smem[buf] + C_::A_FLOATS;
 #pragma unroll
@@ -582,25 +546,8 @@ conv_gemm_kernel(const GemmParams p)
     const int li = lane & 31, lk = lane >> 5;
 
     // LDS -> MFMA fragments for the 8-deep K block kb of buffer `buf`
-    const int fsw = (li >> 2) & 3;      // DMA: swizzle of this lane's fragment rows
     auto load_frag = [&](const float *sa, const float *sb, int kb, float (&af)[TM][4],
                          float (&bf)[TN][4]) {
-        if constexpr (DMA) {
-            const int slot = ((kb * 2 + lk) ^ fsw) * 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float4 v = *reinterpret_cast<const float4 *>(
-                    sa + (wm * (32 * TM) + i * 32 + li) * KB + slot);
-                af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float4 v = *reinterpret_cast<const float4 *>(
-                    sb + (wn * (32 * TN) + j * 32 + li) * KB + slot);
-                bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * (32 * TM) + i * 32 + li;
@@ -629,8 +576,8 @@ conv_gemm_kernel(const GemmParams p)
 
     // one K slice: fragments of block kb+1 are fetched while block kb's MFMAs issue
     auto compute = [&](int buf) {
-        const float *sa = DMA ? &smem_all[0][0][0] + buf * DMA_STAGE : smem[buf];
-        const float *sb = sa + (DMA ? DMA_A_FLOATS : C_::A_FLOATS);
+        const float *sa = smem[buf];
+        const float *sb = smem[buf] + C_::A_FLOATS;
         float af[2][TM][4], bf[2][TN][4];
         load_frag(sa, sb, 0, af[0], bf[0]);
         if (SETPRIO) __builtin_amdgcn_s_setprio(1);
@@ -639,8 +586,8 @@ conv_gemm_kernel(const GemmParams p)
         constexpr int NMFMA = 4 * TM * TN;
         __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
 #pragma unroll
-        for (int kb = 0; kb < KB / 8; ++kb) {
-            if (kb + 1 < KB / 8) load_frag(sa, sb, kb + 1, af[(kb + 1) & 1], bf[(kb + 1) & 1]);
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            if (kb + 1 < BK / 8) load_frag(sa, sb, kb + 1, af[(kb + 1) & 1], bf[(kb + 1) & 1]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -652,7 +599,7 @@ conv_gemm_kernel(const GemmParams p)
             // pin the issue order: the next block's LDS reads ride behind this block's first
             // MFMAs instead of being sunk in front of their consumers (which exposes the
             // LDS latency once per 4 MFMAs)
-            if (kb + 1 < KB / 8) {
+            if (kb + 1 < BK / 8) {
 #define MRCNN_SGB_STEP(q)                                         \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
     __builtin_amdgcn_sched_group_barrier(0x100, (NR + 3 - (q)) / 4, 0);
@@ -670,16 +617,7 @@ conv_gemm_kernel(const GemmParams p)
         load_slice(0);
         store_slice(0);
     }
-    if constexpr (DMA) {
-        // two 16-deep LDS stages filled by LDS-DMA, one barrier per slice: slice kt+1 is in
-        // flight while slice kt's MFMAs run.
-        for (int kt = 0; kt < nslices; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of slice kt
-            __syncthreads();   // slice kt is in LDS for everyone; everyone is done with slice kt-1
-            if (kt + 1 < nslices) load_slice(kt + 1);          // into the stage slice kt-1 used
-            compute(kt & 1);
-        }
-    } else if (SINGLEBUF) {
+    if (SINGLEBUF) {
         // one LDS stage (37 KB -> three workgroups per CU, three waves per SIMD): a wave spends
         // ~40 % of a slice issuing MFMAs and ~60 % staging, so three interleaved waves are
         // needed to keep the pipe full; two barriers per slice instead of one.
@@ -752,7 +690,7 @@ conv_gemm_kernel(const GemmParams p)
         constexpr int LDW = CW + 4;                 // padded LDS row
         constexpr int F4 = CW / 4, RPI = 64 / F4;   // float4 per row, rows per pass of the wave
         constexpr int NK = 32 / RPI;                // passes per 32-row half
-        constexpr int QG = (TM == 2 && !DMA) ? 4 : 2;   // passes whose loads are in flight together (DMA: 128-register budget)
+        constexpr int QG = TM == 2 ? 4 : 2;         // passes whose loads are in flight together
         __syncthreads();                            // every wave is done with the K loop's LDS
         float *ep = &smem_all[0][0][0] + wave * (32 * LDW);
         const int c4 = lane % F4, r_in = lane / F4;
@@ -1030,7 +968,6 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, i
 // Workgroups resident at once: 128x128 tiles run 2 per CU (73 KB LDS), 64x64 tiles 4 per CU.
 constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
 
-int g_lds_dma = 0;     // mrcnn_set_tuning("lds_dma", 0/1): LDS-DMA variant of the forward-form 128x128 kernel
 int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM launch (lowers
                        // the resident workgroups per CU for co-residency experiments)
 
@@ -1040,13 +977,6 @@ void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t
     if constexpr (MODE == WGRAD && !MASKED) {
         if (p.perm_n > 0) {
             hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
-                               dim3((unsigned)tiles, splits), dim3(256), g_extra_lds, s, p);
-            return;
-        }
-    }
-    if constexpr (MODE == FWD && TM == 2 && TN == 2 && !MASKED) {
-        if (g_lds_dma && !p.stem && splits == 1) {
-            hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
                                dim3((unsigned)tiles, splits), dim3(256), g_extra_lds, s, p);
             return;
         }
@@ -1243,8 +1173,7 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
     } else {
         // whole "rounds" of k workgroups per CU (k = 3, 2, 1): pick the round size that leaves
         // the smallest leftover, run the leftover rows as 64x64 tiles
-        const int64_t max_per_cu = (MODE == FWD && g_lds_dma && !is_masked(p) && !p.stem) ? 4
-                                   : single_buffered(2, MODE, is_masked(p)) ? 3 : 2;
+        const int64_t max_per_cu = single_buffered(2, MODE, is_masked(p)) ? 3 : 2;
         int64_t main_tiles_m = tm, best_rem = T;
         for (int64_t k = max_per_cu; k >= 1; --k) {
             const int64_t slots = 256 * k, full = T / slots, rem = T - full * slots;
@@ -1338,10 +1267,6 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     MRCNN_REQUIRE(name != nullptr, "set_tuning: null name");
     if (strcmp(name, "position_major_rows") == 0) {
         g_position_major_rows = value != 0;
-        return 0;
-    }
-    if (strcmp(name, "lds_dma") == 0) {
-        g_lds_dma = value != 0;
         return 0;
     }
     if (strcmp(name, "gemm_extra_lds") == 0) {

@@ -1,4 +1,6 @@
-"""Developer check: the LDS-DMA variant of the forward-form 128x128 kernel (mrcnn_set_tuning
+"""Developer check (historical — needs the library of the commit "Experiment: LDS-DMA ...";
+the variant was removed from csrc/conv_gemm.hip again, results in profiles/r02_exp_lds_dma.log):
+the LDS-DMA variant of the forward-form 128x128 kernel (mrcnn_set_tuning
 "lds_dma") against the register-staged kernel — bit-identical outputs expected (same MFMA
 order; only the staging differs) — on shapes that exercise padding taps, channel tails,
 position-major rows and the fused epilogue; plus timing."""
