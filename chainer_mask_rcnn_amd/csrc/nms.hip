@@ -10,10 +10,14 @@
 //   1. nms_mask_kernel  — one 64-lane wave per (row block, col block) tile of the
 //      upper triangle; lane i owns row box i and emits one uint64 word whose bit
 //      j says IoU(row_i, col_j) >= thresh.  A wave is exactly one mask word wide.
+//      For the diagonal tiles lane j also emits its COLUMN word (bit i: box i < j suppresses
+//      box j) — IoU is symmetric bit for bit, so it is the lower triangle of the same tile.
 //   2. nms_scan_kernel  — one workgroup per NMS problem walks the 64-row chunks:
-//      the in-chunk dependency is resolved in scalar registers from the 64
-//      diagonal words (readlane), then all threads OR the kept rows into the
-//      `removed` bit-vector held in LDS (coalesced row reads).
+//      the in-chunk dependency is resolved by a fixpoint iteration on the column words
+//      (K <- candidates not suppressed by an earlier member of K; one ballot + AND per
+//      iteration, exact: the greedy keep set is its unique fixpoint and iteration t fixes
+//      at least the first t candidates), then all threads OR the kept rows into the
+//      `removed` bit-vector held in LDS (coalesced row reads, all issued together).
 //
 // IoU uses the CPU path's exact fp32 operation sequence (no FMA:
 // -ffp-contract=off), so keep sets are bit-identical to oracle/nms_ref.c.
@@ -35,7 +39,8 @@ __device__ __forceinline__ bool iou_ge(const float4 a, const float area_a, const
 // grid (nblk_max, nblk_max, groups), block 64.
 __global__ void __launch_bounds__(64)
 nms_mask_kernel(const float4 *__restrict__ bbox_all, const int32_t *__restrict__ n_dev, int n_max,
-                int nblk_max, float thresh, uint64_t *__restrict__ mask_all)
+                int nblk_max, float thresh, uint64_t *__restrict__ mask_all,
+                uint64_t *__restrict__ diag_t_all)
 {
     const int cb = blockIdx.x, rb = blockIdx.y, g = blockIdx.z;
     if (cb < rb) return;
@@ -64,6 +69,14 @@ nms_mask_kernel(const float4 *__restrict__ bbox_all, const int32_t *__restrict__
     for (int j = j0; j < ncol; ++j)
         if (iou_ge(a, area_a, cbox[j], carea[j], thresh)) bits |= 1ull << j;
     mask[(int64_t)ri * nblk_max + cb] = bits;
+    if (cb == rb) {
+        // column word of box `lane` inside its own chunk: which earlier boxes suppress it
+        // (iou_ge is symmetric in its two boxes bit for bit: max / min / a + b commute)
+        uint64_t col = 0;
+        for (int i = 0; i < lane; ++i)
+            if (iou_ge(cbox[i], carea[i], a, area_a, thresh)) col |= 1ull << i;
+        diag_t_all[(int64_t)g * n_max + ri] = col;
+    }
 }
 
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
@@ -86,9 +99,9 @@ __device__ __forceinline__ uint64_t readfirstlane64(uint64_t v)
 // into the removed bit-vector with LDS atomics.  The chain per chunk is one global round
 // trip, not one per kept row.
 __global__ void __launch_bounds__(1024)
-nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict__ n_dev,
-                int n_max, int nblk_max, int limit, int32_t *__restrict__ keep_all,
-                int32_t *__restrict__ n_keep_all)
+nms_scan_kernel(const uint64_t *__restrict__ mask_all, const uint64_t *__restrict__ diag_t_all,
+                const int32_t *__restrict__ n_dev, int n_max, int nblk_max, int limit,
+                int32_t *__restrict__ keep_all, int32_t *__restrict__ n_keep_all)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t removed[];
     __shared__ uint64_t s_kept;
@@ -96,6 +109,7 @@ nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict
     const int g = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint64_t *__restrict__ mask = mask_all + (int64_t)g * n_max * nblk_max;
+    const uint64_t *__restrict__ diag_t = diag_t_all + (int64_t)g * n_max;
     int32_t *__restrict__ keep = keep_all + (int64_t)g * n_max;
     const int n = min(n_dev ? n_dev[g] : n_max, n_max);
     const int nblk = (n + 63) / 64;
@@ -104,8 +118,8 @@ nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict
     // rows this wave ORs in: bits j with j % nwaves == wave
     uint64_t mine = 0;
     for (int j = wave; j < 64; j += nwaves) mine |= 1ull << j;
-    uint64_t diag = 0;
-    if (wave == 0 && lane < n) diag = mask[(int64_t)lane * nblk_max];
+    uint64_t col = 0;       // wave 0: column word of row blk * 64 + lane
+    if (wave == 0 && lane < n) col = diag_t[lane];
     __syncthreads();
 
     for (int blk = 0; blk < nblk; ++blk) {
@@ -114,18 +128,18 @@ nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict
             uint64_t rem = readfirstlane64(removed[blk]);
             const int nrow = n - blk * 64;
             if (nrow < 64) rem |= ~((1ull << nrow) - 1ull);
-            uint64_t kept = 0;
-#pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                const uint64_t dj = readlane64(diag, j);
-                if (!((rem >> j) & 1ull)) {
-                    kept |= 1ull << j;
-                    rem |= dj;
-                }
+            // fixpoint: K <- candidates whose column word meets no member of K
+            const uint64_t cand = ~rem;
+            uint64_t kept = cand;
+            for (int it = 0; it < 64; ++it) {
+                const uint64_t sup = __ballot((col & kept) != 0ull);
+                const uint64_t next = cand & ~sup;
+                if (next == kept) break;
+                kept = next;
             }
-            // next chunk's diagonal words: in flight across the barrier and the OR phase
+            // next chunk's column words: in flight across the barrier and the OR phase
             const int nrow_next = row + 64;
-            diag = (blk + 1 < nblk && nrow_next < n) ? mask[(int64_t)nrow_next * nblk_max + blk + 1] : 0ull;
+            col = (blk + 1 < nblk && nrow_next < n) ? diag_t[nrow_next] : 0ull;
             const int cnt = s_count;
             if (limit > 0) {
                 int room = limit - cnt;
@@ -144,20 +158,42 @@ nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict
         if (limit > 0 && cnt >= limit) break;
         const uint64_t k_mine = kept & mine;
         if (k_mine) {
+            // Every load of this phase is issued before any result is used (addresses are
+            // clamped instead of predicated, so there is no branch between the loads): up to
+            // four kept rows x four column words per lane are in flight together and a chunk
+            // costs ONE memory latency.
             const uint64_t *__restrict__ rows = mask + (int64_t)blk * 64 * nblk_max;
-            for (int c = blk + 1 + lane; c < nblk; c += 64) {
-                uint64_t acc = 0;
+            for (int cbase = blk + 1 + lane; cbase < nblk; cbase += 256) {
+                uint64_t acc[4] = {0ull, 0ull, 0ull, 0ull};
                 uint64_t k = k_mine;
                 while (k) {
-                    // up to four independent row loads in flight
-                    const int j0 = __ffsll((long long)k) - 1; k &= k - 1;
-                    uint64_t m0 = rows[(int64_t)j0 * nblk_max + c], m1 = 0, m2 = 0, m3 = 0;
-                    if (k) { const int j1 = __ffsll((long long)k) - 1; k &= k - 1; m1 = rows[(int64_t)j1 * nblk_max + c]; }
-                    if (k) { const int j2 = __ffsll((long long)k) - 1; k &= k - 1; m2 = rows[(int64_t)j2 * nblk_max + c]; }
-                    if (k) { const int j3 = __ffsll((long long)k) - 1; k &= k - 1; m3 = rows[(int64_t)j3 * nblk_max + c]; }
-                    acc |= (m0 | m1) | (m2 | m3);
+                    int j[4];
+                    uint64_t sel[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sel[r] = k ? ~0ull : 0ull;
+                        j[r] = k ? __ffsll((long long)k) - 1 : 0;
+                        k &= k - 1;
+                    }
+                    uint64_t m[4][4];
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci) {
+                        const int c = min(cbase + 64 * ci, nblk - 1);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m[ci][r] = rows[(int64_t)j[r] * nblk_max + c];
+                    }
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci) {
+                        const uint64_t ok = cbase + 64 * ci < nblk ? ~0ull : 0ull;
+                        acc[ci] |= ok & ((m[ci][0] & sel[0]) | (m[ci][1] & sel[1]) |
+                                         (m[ci][2] & sel[2]) | (m[ci][3] & sel[3]));
+                    }
                 }
-                if (acc) atomicOr(reinterpret_cast<unsigned long long *>(&removed[c]), (unsigned long long)acc);
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+                    if (acc[ci])
+                        atomicOr(reinterpret_cast<unsigned long long *>(&removed[cbase + 64 * ci]),
+                                 (unsigned long long)acc[ci]);
             }
         }
         __syncthreads();
@@ -170,7 +206,7 @@ nms_scan_kernel(const uint64_t *__restrict__ mask_all, const int32_t *__restrict
 extern "C" int64_t mrcnn_nms_workspace_bytes(int n_max, int groups)
 {
     const int64_t nblk = (n_max + 63) / 64;
-    return (int64_t)groups * n_max * nblk * 8;
+    return (int64_t)groups * n_max * (nblk + 1) * 8;     // mask rows + one column word per box
 }
 
 extern "C" int mrcnn_nms_sorted_batched(const float *bbox, const int32_t *n_dev, int groups,
@@ -194,13 +230,16 @@ extern "C" int mrcnn_nms_sorted_batched(const float *bbox, const int32_t *n_dev,
         mrcnn::ProfScope prof(mrcnn::PROF_NMS_MASK, 0.,
                               (double)groups * n_max * (16.0 + 4.0 * nblk), s);
         hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, groups), dim3(64), 0, s,
-                           (const float4 *)bbox, n_dev, n_max, nblk, thresh, (uint64_t *)mask_ws);
+                           (const float4 *)bbox, n_dev, n_max, nblk, thresh, (uint64_t *)mask_ws,
+                           (uint64_t *)mask_ws + (int64_t)groups * n_max * nblk);
     }
     mrcnn::ProfScope prof(mrcnn::PROF_NMS_SCAN, 0., (double)groups * n_max * 4.0 * nblk, s);
     // long problems (RPN: 12000 boxes, 2 groups) get 16 waves, short batched ones (per-class
     // NMS: <= 1000 boxes, hundreds of groups) 4
     hipLaunchKernelGGL(nms_scan_kernel, dim3(groups), dim3(nblk > 32 ? 1024 : 256), (size_t)nblk * 8, s,
-                       (const uint64_t *)mask_ws, n_dev, n_max, nblk, limit, keep, n_keep);
+                       (const uint64_t *)mask_ws,
+                       (const uint64_t *)mask_ws + (int64_t)groups * n_max * nblk, n_dev, n_max, nblk,
+                       limit, keep, n_keep);
     return mrcnn::check_launch("nms_sorted");
 }
 
