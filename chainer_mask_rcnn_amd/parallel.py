@@ -49,6 +49,10 @@ class TorchDistExchange(object):
         dist.broadcast(tensor, src=src, group=self.group)
 
     def allreduce_async(self, tensor, bucket_id=0):
+        if tensor.is_cuda:
+            # weight gradients queued on the side stream must be ordered before the collective
+            from .functions.conv import join_wgrad_stream
+            join_wgrad_stream(tensor.device)
         self._works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group,
                                            async_op=True))
 
@@ -67,7 +71,10 @@ class TorchDistExchange(object):
         return None
 
     def describe(self):
-        return dict(library=self.name, ranks=self.world_size)
+        d = dict(library=self.name, ranks=self.world_size)
+        if getattr(self, 'fallback', None):
+            d['fallback'] = self.fallback
+        return d
 
 
 class RcclExchange(object):
@@ -158,10 +165,31 @@ class RcclExchange(object):
 
 
 def default_exchange(group=None):
-    """RCCL behind the C ABI on a ROCm device, torch.distributed (gloo) on CPU."""
-    if torch.cuda.is_available() and group is None:
-        return RcclExchange()
-    return TorchDistExchange(group)
+    """RCCL behind the C ABI on a ROCm device, torch.distributed (gloo) on CPU.
+
+    If creating the C-ABI communicator fails on ANY rank (agreed through the control plane, so
+    no rank is left waiting in a collective), every rank falls back to torch.distributed's own
+    RCCL binding — still RCCL over xGMI, loudly reported (stderr, ``describe()['fallback']``)."""
+    if not (torch.cuda.is_available() and group is None):
+        return TorchDistExchange(group)
+    import sys
+    ex, err = None, ''
+    try:
+        ex = RcclExchange()
+    except Exception as e:                      # noqa: BLE001 — reported below, never silent
+        err = '%s: %s' % (type(e).__name__, e)
+    ok = torch.tensor([1 if ex is not None else 0], dtype=torch.int32)
+    if dist.get_world_size() > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)           # CPU tensor: gloo
+    if int(ok.item()) == 1:
+        return ex
+    if ex is not None:
+        ex.close()
+    sys.stderr.write('[chainer_mask_rcnn_amd.parallel] mrcnn_allreduce_init failed on at least one '
+                     'rank (%s); falling back to torch.distributed nccl (RCCL)\n' % (err or 'peer rank'))
+    fb = TorchDistExchange(None)
+    fb.fallback = err or 'C-ABI communicator failed on a peer rank'
+    return fb
 
 
 # ---------------------------------------------------------------------------------------------
@@ -333,6 +361,11 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        if os.environ['MASTER_ADDR'] in ('127.0.0.1', 'localhost'):
+            # single node: bootstrap sockets on loopback (the container's hostname may not
+            # resolve); the gradient traffic itself goes over xGMI
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+            os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
         if backend is None:
             backend = 'cpu:gloo,cuda:nccl' if torch.cuda.is_available() else 'gloo'
         if 'nccl' in backend:
