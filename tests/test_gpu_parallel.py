@@ -32,20 +32,21 @@ def control_plane():
         s.close()
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
-        dist.init_process_group('gloo', rank=0, world_size=1)
+        torch.cuda.set_device(0)
+        dist.init_process_group('cpu:gloo,cuda:nccl', rank=0, world_size=1)   # as parallel.init_from_env
         created = True
     yield
     if created:
         dist.destroy_process_group()
 
 
-def _run(dev, dp, steps=3, bucket_bytes=4 << 20):
+def _run(dev, dp, steps=3, bucket_bytes=4 << 20, exchange=None):
     model, chain, imgs, bboxes, labels, masks = _build(dev)
     opt = optimizers.MomentumSGD(lr=0.002, momentum=0.9)
     opt.setup(chain)
     opt.add_hook(optimizers.WeightDecay(1e-4))
     freeze_like_reference(model, chain)
-    sync = parallel.DataParallelGradSync(opt, bucket_bytes=bucket_bytes) if dp else None
+    sync = parallel.DataParallelGradSync(opt, bucket_bytes=bucket_bytes, exchange=exchange) if dp else None
     x = torch.tensor(imgs, device=dev)
     np.random.seed(5)
     losses = []
@@ -125,3 +126,13 @@ def test_buckets_launch_during_backward(dev, control_plane):
     n = len(sync.buckets.bounds)
     assert seen['launched_before_finish'] >= n - 1, (seen, n)
     sync.exchange.close()
+
+
+def test_fallback_exchange_one_rank_bit_identical(dev, control_plane):
+    """The library fallback of parallel.default_exchange (torch.distributed's own RCCL binding,
+    used only if mrcnn_allreduce_init fails on some rank) drives the same buckets and poll
+    points: bit-identical to the plain path with one rank."""
+    l_ref, w_ref, _, _ = _run(dev, dp=False)
+    l_fb, w_fb, sync, _ = _run(dev, dp=True, exchange=parallel.TorchDistExchange())
+    assert l_fb == l_ref and torch.equal(w_fb, w_ref)
+    assert sync.describe()['library'].startswith('torch.distributed')
