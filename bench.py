@@ -63,7 +63,7 @@ def synthetic_batch(rng, batch, H, W, n_gt=8, n_fg_class=80):
     return imgs, bboxes, labels, masks, scales
 
 
-def build_trainer(n_layers, device, world, lr_batch, force_dp=False, bucket_bytes=16 << 20):
+def build_trainer(n_layers, device, world, lr_batch, force_dp=False, bucket_bytes=16 << 20, defer=0):
     import chainer_mask_rcnn_amd as cmr
     from chainer_mask_rcnn_amd import optimizers, parallel
     # examples/coco/train.py:36-38 + examples/train_common.py:160-169
@@ -88,6 +88,12 @@ def build_trainer(n_layers, device, world, lr_batch, force_dp=False, bucket_byte
     sync = None
     if world > 1 or force_dp:
         sync = parallel.DataParallelGradSync(opt, bucket_bytes=bucket_bytes)
+    if defer > 0:
+        # hold the weight gradients (+ update) of the first res5 block's 3x3 / 1x1 back into the
+        # next step's proposal window, where the GPU is otherwise nearly idle (optimizers.py)
+        a, b1 = model.head.res5.a, model.head.res5.b1
+        opt.defer_weight_gradients([a.conv2.W, a.conv1.W, a.conv3.W, a.conv4.W, b1.conv2.W,
+                                    b1.conv1.W, b1.conv3.W][:defer])
     return model, chain, opt, sync
 
 
@@ -320,6 +326,9 @@ def main():
                          'over K pre-generated host batches with the image upload inside the '
                          'timed region (the reference converter uploads every iteration, '
                          'examples/train_common.py:219-225); 0 = skip')
+    ap.add_argument('--defer-wgrad', type=int, default=5,
+                    help='number of res5 weight gradients (a.conv2, a.conv1, a.conv3, a.conv4, b1.conv2, ...) held back into the '
+                         "next step's proposal window (single-GPU runs; 0 = off)")
     ap.add_argument('--tune', default='',
                     help='developer: comma-separated mrcnn_set_tuning knobs, e.g. small_m_split=4')
     ap.add_argument('--bucket-mb', type=float, default=16.0,
@@ -372,13 +381,15 @@ def main():
     model, chain, opt, sync = build_trainer(args.layers, device, world,
                                             args.lr_batch or args.batch * world,
                                             force_dp=args.force_dp,
-                                            bucket_bytes=parallel_bucket_bytes)
+                                            bucket_bytes=parallel_bucket_bytes,
+                                            defer=args.defer_wgrad)
     imgs_d = torch.tensor(imgs, device=device).contiguous(memory_format=torch.channels_last)
 
     def step():
         return opt.update(chain, imgs_d, bboxes, labels, masks, scales)
 
     def fence():
+        opt.flush()                 # deferred weight gradients / updates belong to the region
         torch.cuda.synchronize()
         if sync is not None and world > 1:
             sync.exchange.barrier()               # RCCL all-reduce + device synchronise
@@ -500,6 +511,7 @@ def main():
                         args.layers, '+RCCL all-reduce' if sync is not None else '',
                         args.batch, args.height, args.width, n_rois),
             input='resident', global_batch=global_batch, rois_per_image=n_rois // args.batch,
+            deferred_weight_gradients=len(opt.deferred_params),
             parallelism='dp%d' % world,
             loss=round(loss_val, 5) if np.isfinite(loss_val) else None,
             # reference algorithm (mask branch on all 512 RoIs/img)

@@ -375,11 +375,49 @@ def join_wgrad_stream(device=None):
             torch.cuda.current_stream(st.device).wait_stream(st)
 
 
+# ---- weight gradients deferred into the next step's proposal window --------------------------
+# Between the RPN convolution and the RoI head of a train step the GPU is nearly idle: the
+# proposal kernels (top-k, NMS scan: two workgroups) run, then the host samples the RoIs
+# (~2 ms together).  The RoI head's weights are not read before that window has passed, so the
+# weight gradients of some head layers — and the SGD update of exactly those parameters — can be
+# held back at the end of a step and run INSIDE the next step's window on a second stream, where
+# they cost nothing (optimizers.MomentumSGD.defer_weight_gradients; same gradients, same update,
+# applied before the parameter is read again: results are bit-identical).
+class DeferQueue(object):
+    def __init__(self, params):
+        self.ids = set(id(p) for p in params)
+        self.jobs = []
+
+
+_DEFER = None          # set by MomentumSGD.update around backward
+_defer_streams = {}
+
+
+def defer_stream(device):
+    key = str(device)
+    if key not in _defer_streams:
+        _defer_streams[key] = torch.cuda.Stream(device=device)
+    return _defer_streams[key]
+
+
+def run_deferred_wgrads(jobs):
+    """Launch the held-back weight gradients on the current stream (the caller selects it)."""
+    for d, x, g, gW, mask_y, in_scale, row_scale in jobs:
+        ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
+                            g.device, 'wgrad-defer')
+        _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(g), _lib.ptr(gW),
+                  _lib.ptr(ws), _lib.ptr(mask_y), _lib.ptr(in_scale), _lib.ptr(row_scale),
+                  _lib.stream_ptr())
+
+
 def _wgrad_raw(d, x, g, W, mask_y, in_scale, side=None, row_scale=None):
     """Returns the tensor autograd should see for W (None when written in place).  With
     ``side`` (a stream) the launch is queued there, ordered after everything queued so far
     on the current stream; only arena-backed (direct) gradients may use it."""
     direct = _direct_grad(W)
+    if direct and _DEFER is not None and id(W) in _DEFER.ids:
+        _DEFER.jobs.append((d, x, g, W.grad, mask_y, in_scale, row_scale))
+        return None
     gW = W.grad if direct else empty_nhwc(tuple(W.shape), g.device)
     if side is not None and direct:
         side.wait_stream(torch.cuda.current_stream(g.device))

@@ -267,6 +267,8 @@ class MaskRCNN(torch.nn.Module):
         roi_mask_logits[i] is (D_i, n_fg_class, 14, 14).  ``return_intermediates`` appends a
         dict with the head outputs the detections were computed from (``roi_cls_locs``,
         ``roi_scores``, ``rois``, ``roi_indices`` device tensors, ``feature_shape``)."""
+        from .. import optimizers
+        optimizers.flush_all()             # no parameter update may be pending while predicting
         was_training = self.training
         self.eval()
         try:

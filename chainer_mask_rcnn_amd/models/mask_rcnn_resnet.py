@@ -74,6 +74,8 @@ class ResNetRoIHead(torch.nn.Module):
 
         ``mask_rows`` (extension): int64 index tensor of the RoI rows the mask branch is run
         for; ``roi_masks`` then has ``len(mask_rows)`` rows.  ``None`` = all rows."""
+        from .. import optimizers
+        optimizers.join_pending_all()      # deferred updates of the head's parameters (if any)
         roi_indices = roi_indices.to(torch.float32)
         indices_and_rois = torch.cat((roi_indices[:, None], rois), dim=1)
         res5_stride = self.roi_size // 7

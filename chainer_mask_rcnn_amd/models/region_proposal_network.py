@@ -70,12 +70,19 @@ class RegionProposalNetwork(torch.nn.Module):
         rpn_locs = nhwc[..., :4 * A].reshape(n, -1, 4)
         rpn_scores = nhwc[..., 4 * A:5 * A].reshape(n, -1)
 
+        # the proposal window opens (top-k / NMS + the host's RoI sampling: the GPU is nearly
+        # idle): weight gradients the optimizer held back from the previous step run here
+        from .. import optimizers
+        if optimizers.DEFER_LAUNCH_AT == 'window-open':
+            optimizers.launch_pending_all()
         self.proposal_layer.train = self.training
         if hasattr(self.proposal_layer, 'batch'):
             rois = self.proposal_layer.batch(rpn_locs, rpn_scores, anchor, img_size, scales)
         else:
             rois = [self.proposal_layer(rpn_locs[i], rpn_scores[i], anchor, img_size,
                                         scale=float(scales[i])) for i in range(n)]
+        if optimizers.DEFER_LAUNCH_AT != 'window-open':
+            optimizers.launch_pending_all()    # the proposal read-back has returned: GPU idle
         self.last_counts = [int(len(roi)) for roi in rois]     # host-known: no read-back
         roi_indices = [torch.full((len(roi),), i, dtype=torch.int32, device=x.device)
                        for i, roi in enumerate(rois)]

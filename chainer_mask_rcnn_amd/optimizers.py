@@ -20,6 +20,13 @@ Gradient ownership rules (chainer semantics, ``Optimizer.update`` / ``GradientMe
   no momentum decay — exactly like chainer skips ``param.grad is None``;
 * ``p.grad`` must keep aliasing the arena: ``update()`` re-binds it if the caller replaced or
   dropped it (``zero_grad(set_to_none=True)``), folding a foreign gradient in first.
+
+Deferred weight gradients (opt-in, ``defer_weight_gradients``): the weight gradients of chosen
+RoI-head layers and the update of exactly those parameters are held back at the end of a step
+and run on a second stream inside the NEXT step's proposal window (between the RPN convolution
+and the RoI head, where the GPU is otherwise nearly idle).  The parameters are updated before
+they are read again, so every step computes the same values; ``flush()`` forces pending work
+(called by ``predict``, the serializers and at the end of a timed region).
 """
 import torch
 
@@ -139,6 +146,9 @@ class MomentumSGD(object):
         self.arena = None
         self.grad_sync = None      # set by parallel.DataParallelGradSync
         self.t = 0
+        self.deferred_params = []  # see defer_weight_gradients
+        self._pending = None       # (jobs, [(lo, hi)], lr, momentum, wd, grad_scale)
+        self._join = None          # event the compute stream must wait for before the head
 
     def setup(self, link):
         self.target = link
@@ -149,6 +159,55 @@ class MomentumSGD(object):
             self.weight_decay = hook.rate
         else:
             raise TypeError('unsupported optimizer hook: %r' % (hook,))
+
+    def defer_weight_gradients(self, params):
+        """Hold the weight gradients (and the update) of ``params`` — parameters of the RoI
+        head only: they must not be read between the end of a step and the next step's RoI
+        head — back into the next step's proposal window.  Under data parallelism their
+        gradient slices are all-reduced there too (call this BEFORE the first update: the
+        gradient buckets are planned around them)."""
+        self.deferred_params = list(params)
+        if self not in _DEFERRING:
+            _DEFERRING.append(self)
+
+    # -- pending work ------------------------------------------------------------------------
+    def launch_pending(self):
+        """Queue the held-back weight gradients + their SGD slices on the defer stream, ordered
+        after everything queued so far on the compute stream."""
+        if self._pending is None:
+            return
+        from .functions import conv
+        jobs, runs, lr, momentum, wd, scale = self._pending
+        self._pending = None
+        a = self.arena
+        dev = a.values.device
+        side, main = conv.defer_stream(dev), torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            conv.run_deferred_wgrads(jobs)
+            if self.grad_sync is not None:          # data parallel: sum over ranks first
+                self.grad_sync.reduce_deferred([a.grads[lo:hi] for lo, hi in runs])
+            for lo, hi in runs:
+                _lib.call('mrcnn_sgd_momentum_wd_ex', _lib.ptr(a.values[lo:hi]),
+                          _lib.ptr(a.grads[lo:hi]), _lib.ptr(a.momenta[lo:hi]), hi - lo,
+                          float(lr), float(momentum), float(wd), float(scale), 1, _lib.stream_ptr())
+            for job in jobs:                       # keep the operands alive until S2 is done
+                for t in job[1:]:
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(side)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._join = ev
+
+    def join_pending(self):
+        """The compute stream waits for the deferred work (before the parameters are read)."""
+        if self._join is not None:
+            torch.cuda.current_stream(self.arena.values.device).wait_event(self._join)
+            self._join = None
+
+    def flush(self):
+        self.launch_pending()
+        self.join_pending()
 
     def _build(self):
         never, affine = _gradient_free_parameters(self.target)
@@ -178,20 +237,29 @@ class MomentumSGD(object):
         if self.arena is None:
             self._build()
         loss = None
+        defer = None
         if lossfun is not None:
-            loss = lossfun(*args, **kwds)
+            loss = lossfun(*args, **kwds)      # (launches / joins the previous step's deferred work)
+            self.flush()                       # nothing may stay pending across a backward
             if self.grad_sync is not None:
                 self.grad_sync.begin_backward()
-            loss.backward()
+            from .functions import conv
+            if self.deferred_params and (self.grad_sync is None or
+                                         getattr(self.grad_sync, 'supports_deferred', False)):
+                defer = conv._DEFER = conv.DeferQueue(self.deferred_params)
+            try:
+                loss.backward()
+            finally:
+                conv._DEFER = None
         from .functions.conv import join_wgrad_stream
         join_wgrad_stream()            # weight gradients queued on the side stream
         scale = 1.0
         if self.grad_sync is not None:
             scale = self.grad_sync.finish()
-        self.step(scale, zero_grads=True)
+        self.step(scale, zero_grads=True, deferred=defer)
         return loss
 
-    def step(self, grad_scale=1.0, zero_grads=False):
+    def step(self, grad_scale=1.0, zero_grads=False, deferred=None):
         """Apply the update rule to every parameter that received a gradient since the last
         step (one launch when that is all of them: the normal case).  ``zero_grads`` clears
         the gradient arena in the same pass."""
@@ -202,17 +270,57 @@ class MomentumSGD(object):
             # after the all-reduce every slice holds the sum over ranks (zeros from a rank whose
             # backward skipped the parameter): all ranks update everything, no host round trip
             written = [True] * len(written)
-        runs = _runs(written)
+        held = set()
+        if deferred is not None and deferred.jobs:
+            # parameters whose gradient kernels were held back: their slices are updated by
+            # launch_pending(), after those kernels, in the next step's proposal window
+            grads = set(j[3].data_ptr() for j in deferred.jobs)
+            held = set(i for i, p in enumerate(a.params) if p.grad.data_ptr() in grads)
+            self._pending = (deferred.jobs,
+                             [a.slice_bounds(f, l) for f, l in _runs([i in held for i in range(len(a.params))])],
+                             self.lr, self.momentum, self.weight_decay, grad_scale)
+        all_written = all(written)
+        runs = _runs([w and i not in held for i, w in enumerate(written)])
         for first, last in runs:
             lo, hi = a.slice_bounds(first, last)
             _lib.call('mrcnn_sgd_momentum_wd_ex', _lib.ptr(a.values[lo:hi]),
                       _lib.ptr(a.grads[lo:hi]), _lib.ptr(a.momenta[lo:hi]), hi - lo,
                       float(self.lr), float(self.momentum), float(self.weight_decay),
                       float(grad_scale), 1 if zero_grads else 0, _lib.stream_ptr())
-        if zero_grads and runs != [(0, len(a.params) - 1)]:
+        if zero_grads and not all_written:
             a.grads.zero_()              # slices of skipped parameters (normally there are none)
         a.epoch += 1
         self.t += 1
+
+
+_DEFERRING = []       # optimizers that may hold deferred work (see defer_weight_gradients)
+# where the held-back work is queued: 'window-open' = right behind the RPN convolutions, beside
+# the top-k / NMS kernels (measured best: 49.6-50.0 vs 50.6-51.2 ms per step without deferral);
+# 'after-proposals' = once the proposal read-back has returned (50.0-50.6).  Running the proposal
+# kernels on a separate high-priority stream next to the deferred work was measured and dropped
+# (64 ms per step).
+import os as _os
+DEFER_LAUNCH_AT = _os.environ.get('MRCNN_DEFER_AT', 'window-open')
+
+
+def launch_pending_all():
+    """Called by the RPN right after its convolutions are queued: the proposal window opens."""
+    for opt in _DEFERRING:
+        opt.launch_pending()
+
+
+def join_pending_all():
+    """Called by the RoI head before it reads its parameters."""
+    for opt in _DEFERRING:
+        opt.join_pending()
+
+
+def flush_all():
+    """Force every pending deferred update (anything that reads parameters outside a train
+    step: predict, snapshots)."""
+    for opt in _DEFERRING:
+        if opt.arena is not None:
+            opt.flush()
 
 
 def _runs(flags):

@@ -254,6 +254,17 @@ def plan_buckets(arena, units, bucket_bytes):
     return buckets
 
 
+class _ArenaRange(object):
+    """View of the parameters [first, last] of an arena with plan_buckets' interface."""
+
+    def __init__(self, arena, first, last):
+        self.arena, self.first = arena, first
+        self.params = arena.params[first:last + 1]
+
+    def slice_bounds(self, a, b):
+        return self.arena.slice_bounds(self.first + a, self.first + b)
+
+
 class DataParallelGradSync(object):
     """Hooks a MomentumSGD to an exchange: rank-0 broadcast at attach, bucketed all-reduce
     of the gradient arena overlapped with backward, 1/world scale handed to the SGD launch."""
@@ -296,7 +307,23 @@ class DataParallelGradSync(object):
             for p in m.parameters(recurse=False):
                 owner.setdefault(id(p), id(m))
         units = [owner.get(id(p), id(p)) for p in arena.params]
-        self.bucket_params = plan_buckets(arena, units, self.bucket_bytes)
+        # parameters whose weight gradients the optimizer holds back into the next step's
+        # proposal window (optimizers.defer_weight_gradients) are reduced there, on their own:
+        # the in-backward buckets are planned over the remaining runs of the arena
+        held = set(id(p) for p in getattr(optimizer, 'deferred_params', []))
+        self.bucket_params = []
+        i, n = 0, len(arena.params)
+        while i < n:
+            if id(arena.params[i]) in held:
+                i += 1
+                continue
+            j = i
+            while j + 1 < n and id(arena.params[j + 1]) not in held:
+                j += 1
+            sub = _ArenaRange(arena, i, j)
+            self.bucket_params += [(i + a, i + b) for a, b in plan_buckets(sub, units[i:j + 1],
+                                                                           self.bucket_bytes)]
+            i = j + 1
         bounds = [arena.slice_bounds(a, b) for a, b in self.bucket_params]
         self.buckets = GradBuckets(arena.grads, bounds, exchange=self.exchange)
         # poll points inside backward (duck-typed: a MaskRCNNTrainChain around a MaskRCNNResNet)
@@ -336,6 +363,15 @@ class DataParallelGradSync(object):
 
     def stage_hook(self, stage_index=None):
         return self._tensor_hook
+
+    supports_deferred = True
+
+    def reduce_deferred(self, flat_slices):
+        """All-reduce the gradient slices of held-back parameters on the CURRENT stream (the
+        optimizer's defer stream, after their weight-gradient kernels) and make it wait."""
+        for k, t in enumerate(flat_slices):
+            self.exchange.allreduce_async(t, 1000 + k)
+        self.exchange.wait_all()
 
     def finish(self):
         """Wait for every bucket; returns the scale (1/world) to apply to the sums."""

@@ -25,6 +25,8 @@ def _fused_parts(model):
 
 def state_arrays(model):
     """{chainer key: ndarray} for every parameter of a MaskRCNNResNet."""
+    from . import optimizers
+    optimizers.flush_all()                 # deferred parameter updates, if any
     fused = _fused_parts(model)
     out = {}
     for name, p in model.named_parameters():

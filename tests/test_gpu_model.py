@@ -339,3 +339,38 @@ def test_optimizer_ownership_rules(dev):
     torch.cuda.synchronize()
     scale = float(g_once.abs().max())
     assert float((arena.grads - 2 * g_once).abs().max()) <= 1e-5 * scale
+
+
+def test_deferred_weight_gradients_are_results_identical(dev):
+    """MomentumSGD.defer_weight_gradients: the weight gradients (and the update) of chosen RoI
+    head layers run in the NEXT step's proposal window on a second stream.  Same losses every
+    step and, after flush(), bit-identical weights and momenta."""
+    def run(defer):
+        model, chain, imgs, bboxes, labels, masks = _build(dev)
+        opt = optimizers.MomentumSGD(lr=0.002, momentum=0.9)
+        opt.setup(chain)
+        opt.add_hook(optimizers.WeightDecay(1e-4))
+        freeze_like_reference(model, chain)
+        if defer:
+            a = model.head.res5.a
+            opt.defer_weight_gradients([a.conv2.W, a.conv1.W])
+        x = torch.tensor(imgs, device=dev)
+        np.random.seed(5)
+        losses = [opt.update(chain, x, bboxes, labels, masks, [1., 1.]).item() for _ in range(4)]
+        pending = opt._pending is not None
+        opt.flush()
+        torch.cuda.synchronize()
+        return losses, opt.arena.values.clone(), opt.arena.momenta.clone(), pending, opt
+    l0, w0, v0, p0, _ = run(False)
+    l1, w1, v1, p1, opt = run(True)
+    assert not p0 and p1                       # work really was held back across the step boundary
+    assert l1 == l0
+    assert torch.equal(w1, w0) and torch.equal(v1, v0)
+    assert float(opt.arena.grads.abs().max()) == 0.    # every slice cleared by its own SGD launch
+    # anything that reads parameters outside a train step flushes first
+    np.random.seed(5)
+    opt.update(opt.target, torch.tensor(_build(dev)[2], device=dev), *_build(dev)[3:], [1., 1.])
+    assert opt._pending is not None
+    from chainer_mask_rcnn_amd import serializers
+    serializers.state_arrays(opt.target.mask_rcnn)
+    assert opt._pending is None and opt._join is None

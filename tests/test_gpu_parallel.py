@@ -40,18 +40,22 @@ def control_plane():
         dist.destroy_process_group()
 
 
-def _run(dev, dp, steps=3, bucket_bytes=4 << 20, exchange=None):
+def _run(dev, dp, steps=3, bucket_bytes=4 << 20, exchange=None, defer=False):
     model, chain, imgs, bboxes, labels, masks = _build(dev)
     opt = optimizers.MomentumSGD(lr=0.002, momentum=0.9)
     opt.setup(chain)
     opt.add_hook(optimizers.WeightDecay(1e-4))
     freeze_like_reference(model, chain)
+    if defer:
+        a = model.head.res5.a
+        opt.defer_weight_gradients([a.conv2.W, a.conv1.W, a.conv3.W, a.conv4.W])
     sync = parallel.DataParallelGradSync(opt, bucket_bytes=bucket_bytes, exchange=exchange) if dp else None
     x = torch.tensor(imgs, device=dev)
     np.random.seed(5)
     losses = []
     for _ in range(steps):
         losses.append(opt.update(chain, x, bboxes, labels, masks, [1., 1.]).item())
+    opt.flush()
     torch.cuda.synchronize()
     return losses, opt.arena.values.clone(), sync, opt
 
@@ -136,3 +140,18 @@ def test_fallback_exchange_one_rank_bit_identical(dev, control_plane):
     l_fb, w_fb, sync, _ = _run(dev, dp=True, exchange=parallel.TorchDistExchange())
     assert l_fb == l_ref and torch.equal(w_fb, w_ref)
     assert sync.describe()['library'].startswith('torch.distributed')
+
+
+def test_deferred_weight_gradients_under_data_parallel(dev, control_plane):
+    """Held-back weight gradients are all-reduced (C-ABI RCCL, on the defer stream) and applied
+    in the next step's proposal window; the in-backward buckets are planned around them."""
+    l_ref, w_ref, _, _ = _run(dev, dp=False)
+    l_dp, w_dp, sync, opt = _run(dev, dp=True, defer=True)
+    assert l_dp == l_ref and torch.equal(w_dp, w_ref)
+    held = set(id(p) for p in opt.deferred_params)
+    covered = set()
+    for lo, hi in sync.bucket_params:
+        covered.update(range(lo, hi + 1))
+    for i, p in enumerate(opt.arena.params):
+        assert (i in covered) != (id(p) in held)        # every parameter exactly one way
+    sync.exchange.close()
