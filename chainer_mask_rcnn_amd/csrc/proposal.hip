@@ -95,21 +95,23 @@ __global__ void topk_keys_kernel(const float *__restrict__ score,
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, (int)__popcll(b));
 }
 
-// start[b] = number of keys in buckets above b (one workgroup of 1024 threads)
-__global__ void __launch_bounds__(1024)
+// start[b] = number of keys in buckets above b (one workgroup of kScanThreads threads: four
+// waves find room on a CU that a register-heavy GEMM of another stream shares, sixteen do not)
+constexpr int kScanThreads = 256;
+__global__ void __launch_bounds__(kScanThreads)
 topk_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ start, int64_t ws_stride)
 {
     hist = grp(hist, ws_stride); start = grp(start, ws_stride);
-    __shared__ int part[1024];
+    __shared__ int part[kScanThreads];
     const int t = threadIdx.x;
-    constexpr int PER = kBuckets / 1024;
+    constexpr int PER = kBuckets / kScanThreads;
     // thread t owns buckets [hi - PER + 1, hi], hi descending with t
     const int hi = kBuckets - 1 - t * PER;
     int sum = 0;
     for (int j = 0; j < PER; ++j) sum += hist[hi - j];
     part[t] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
+    for (int off = 1; off < kScanThreads; off <<= 1) {
         const int v = t >= off ? part[t - off] : 0;
         __syncthreads();
         part[t] += v;
@@ -272,7 +274,7 @@ extern "C" int mrcnn_topk_desc_batched(const float *score, const uint8_t *valid,
     mrcnn::ProfScope prof(mrcnn::PROF_TOPK, 0., groups * (40.0 * n + 3.0 * 4 * kBuckets), s);
     hipLaunchKernelGGL(topk_keys_kernel, dim3(blocks, 1, G), dim3(256), 0, s, score, valid, n, keys,
                        hist, n_valid, ws_stride);
-    hipLaunchKernelGGL(topk_scan_kernel, dim3(1, 1, G), dim3(1024), 0, s, hist, start, ws_stride);
+    hipLaunchKernelGGL(topk_scan_kernel, dim3(1, 1, G), dim3(kScanThreads), 0, s, hist, start, ws_stride);
     hipLaunchKernelGGL(topk_place_kernel, dim3(blocks, 1, G), dim3(256), 0, s, keys, n, hist, start,
                        sorted, ws_stride);
     hipLaunchKernelGGL(topk_rank_kernel, dim3(blocks, kRankSplits, G), dim3(256), 0, s, sorted,
