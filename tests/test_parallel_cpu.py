@@ -184,6 +184,33 @@ def _sync_worker(rank, world, port, q):
     ok = ok and abs(scale - 1.0 / world) < 1e-12
     total = float(sum(range(1, world + 1)))
     ok = ok and all(bool((p.grad == total).all()) for p in a.params)
+
+    # held-back (deferred) parameters: left out of the in-backward buckets, reduced on their own
+    chain2 = Chain()
+    opt2 = optimizers.MomentumSGD(lr=0.1)
+    opt2.setup(chain2)
+    net2 = chain2.mask_rcnn
+    opt2.defer_weight_gradients([net2.rpn.W, net2.rpn.b])
+    ex2 = Recording()
+    sync2 = parallel.DataParallelGradSync(opt2, exchange=ex2, bucket_bytes=64)
+    opt2._build()
+    a2 = opt2.arena
+    held = set(id(p) for p in opt2.deferred_params)
+    covered = set()
+    for lo, hi in sync2.bucket_params:
+        covered.update(range(lo, hi + 1))
+    ok = ok and all((i in covered) != (id(p) in held) for i, p in enumerate(a2.params))
+    a2.grads.fill_(float(rank + 1))
+    for p in a2.params:
+        if id(p) not in held:
+            a2.claim(p)
+    sync2.finish()                                  # every regular bucket, none of the held slices
+    idx = [i for i, p in enumerate(a2.params) if id(p) in held]
+    lo, hi = a2.slice_bounds(idx[0], idx[-1])
+    ok = ok and bool((a2.grads[lo:hi] == float(rank + 1)).all())
+    ok = ok and bool((a2.grads[:lo] == total).all()) and bool((a2.grads[hi:] == total).all())
+    sync2.reduce_deferred([a2.grads[lo:hi]])        # what MomentumSGD.launch_pending does
+    ok = ok and bool((a2.grads == total).all()) and ex2.log[-1] >= 1000
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
