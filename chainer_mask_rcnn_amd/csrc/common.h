@@ -45,7 +45,8 @@ static inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 enum ProfKind {
     PROF_CONV_FWD_128 = 0, PROF_CONV_FWD_64, PROF_CONV_DGRAD_128, PROF_CONV_DGRAD_64,
     PROF_CONV_WGRAD_128, PROF_CONV_WGRAD_64, PROF_ROI_ALIGN_FWD, PROF_ROI_ALIGN_BWD,
-    PROF_NMS_MASK, PROF_NMS_SCAN, PROF_TOPK, PROF_SGD, PROF_ELEMENTWISE, PROF_NUM_KINDS
+    PROF_NMS_MASK, PROF_NMS_SCAN, PROF_TOPK, PROF_SGD, PROF_ELEMENTWISE, PROF_WINO_TRANSFORM,
+    PROF_NUM_KINDS
 };
 bool prof_enabled(int kind);
 void prof_begin(int kind, double flops, double bytes, hipStream_t s);

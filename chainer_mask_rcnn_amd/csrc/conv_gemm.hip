@@ -141,6 +141,10 @@ struct GemmParams {
     const float *res_g, *res_y, *out_mask_y;
     float *split_ws;     // host only: caller's split-K workspace (kSplitWsBytes) or NULL
     unsigned a_bytes, b_bytes, c_bytes;  // buffer extents (bytes) of A (and mask_y), B, C
+    // Batched launches (gridDim.z > 1; the 36 per-frequency GEMMs of the Winograd path,
+    // winograd.hip): floats between consecutive problems of A, B and C.  The extents above
+    // are then per problem.
+    int64_t batch_a, batch_b, batch_c;
 };
 
 #ifdef MRCNN_GEMM_TRACE
@@ -242,8 +246,9 @@ conv_gemm_kernel(const GemmParams p)
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, p.a_bytes);
-    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B, p.b_bytes);
+    const int64_t zb = blockIdx.z;                      // batched launches: problem index
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + zb * p.batch_a, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B + zb * p.batch_b, p.b_bytes);
     const __amdgpu_buffer_rsrc_t rMask = make_rsrc(p.mask_y, p.a_bytes);
     const bool use_mask = HAS_MASK && p.mask_y != nullptr;
 
@@ -665,7 +670,7 @@ conv_gemm_kernel(const GemmParams p)
     // ---------------- epilogue ------------------------------------------------------
     // Per 32x32 MFMA tile: compute the 16 element offsets, issue every auxiliary load
     // (residual / accumulate / shortcut gradient) back to back, then combine and store.
-    const float *out_base = p.C;
+    const float *out_base = p.C + zb * p.batch_c;
     out_base += (int64_t)split * p.split_stride;
     const __amdgpu_buffer_rsrc_t rC = make_rsrc(out_base, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rRes = make_rsrc(p.residual, p.c_bytes);
@@ -972,26 +977,26 @@ int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM 
                        // the resident workgroups per CU for co-residency experiments)
 
 template <int TM, int TN, int MODE, bool MASKED>
-void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t s)
+void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t s, int batch = 1)
 {
     if constexpr (MODE == WGRAD && !MASKED) {
         if (p.perm_n > 0) {
             hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
-                               dim3((unsigned)tiles, splits), dim3(256), g_extra_lds, s, p);
+                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
             return;
         }
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED>), dim3((unsigned)tiles, splits),
-                       dim3(256), g_extra_lds, s, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED>),
+                       dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
 }
 
 inline bool is_masked(const GemmParams &p) { return p.mask_y != nullptr || p.in_scale != nullptr; }
 
 template <int TM, int TN, int MODE>
-void launch_kernel(const GemmParams &p, int64_t tiles, int splits, hipStream_t s)
+void launch_kernel(const GemmParams &p, int64_t tiles, int splits, hipStream_t s, int batch = 1)
 {
-    if (is_masked(p)) launch_kernel_m<TM, TN, MODE, true>(p, tiles, splits, s);
-    else launch_kernel_m<TM, TN, MODE, false>(p, tiles, splits, s);
+    if (is_masked(p)) launch_kernel_m<TM, TN, MODE, true>(p, tiles, splits, s, batch);
+    else launch_kernel_m<TM, TN, MODE, false>(p, tiles, splits, s, batch);
 }
 
 template <int TM, int TN, int MODE>
@@ -1657,3 +1662,5 @@ extern "C" int mrcnn_deconv2x2s2_wgrad(const float *x, const float *gy, float *g
     return wgrad_impl(x, C, gy, gw, C, (int64_t)N * H * W, N, 2 * H, 2 * W, K, H, W, 2, 2, 2, 0, ws,
                       mrcnn::as_stream(stream));
 }
+
+#include "conv_winograd.h"

@@ -72,7 +72,7 @@ static const char *kProfNames[mrcnn::PROF_NUM_KINDS] = {
     "conv_gemm_kernel<2,2,FWD>", "conv_gemm_kernel<1,1,FWD>", "conv_gemm_kernel<2,2,DGRAD>",
     "conv_gemm_kernel<1,1,DGRAD>", "conv_gemm_kernel<2,2,WGRAD>", "conv_gemm_kernel<1,1,WGRAD>",
     "roi_align_fwd_kernel", "roi_align_bwd_kernel", "nms_mask_kernel", "nms_scan_kernel",
-    "topk_rank_kernel", "sgd_kernel", "elementwise"};
+    "topk_rank_kernel", "sgd_kernel", "elementwise", "wino_transform_kernels"};
 
 extern "C" int mrcnn_profile_enable(int on)
 {

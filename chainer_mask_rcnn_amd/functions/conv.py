@@ -289,7 +289,7 @@ def _stage_transposes(blocks, scales, device):
         s3, s4 = scales[bi]
         for key, W, d, sc in (('1', W1, d1, None), ('2', W2, d2, None), ('3', W3, d3, s3),
                               ('4', W4, d4, s4)):
-            if W is not None and _uses_transposed_dgrad(d):
+            if W is not None and _uses_transposed_dgrad(d) and not uses_winograd(d):
                 jobs.append((bi, key, nhwc(W), d, sc))
     out = [dict() for _ in blocks]
     if not jobs:
@@ -345,6 +345,69 @@ def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, acc
               _lib.ptr(res_y), _lib.ptr(out_mask_y), _lib.ptr(out_scale),
               _lib.ptr(split_ws(g.device)), _lib.stream_ptr())
     return gx
+
+
+# ---- Winograd F(4x4,3x3) path (csrc/conv_winograd.h) ------------------------------------------
+# The RoI head's 3x3 convolutions run on ~1000 maps of 7x7: padded to 8x8 that is four 4x4
+# output tiles per map, 144 multiply-adds per (map, c, k) instead of the direct form's 441.
+# Selected for 3x3 / stride 1 / pad 1 layers over many small maps; the backbone's large maps keep
+# the implicit-GEMM kernel.  fp32 throughout; error 3.4e-6 of the tensor scale (direct: 3.5e-7),
+# parity tolerance 1e-4.
+USE_WINOGRAD = True
+# Which passes take the Winograd route.  Backward-data and backward-filter always do: their
+# extra rounding (3e-6 of the gradient tensor's scale) is invisible next to the fp32 floor of
+# the whole-graph gradients (tools/grad_floor.py: identical per-layer errors with and without).
+# The FORWARD of a train step does not: a Winograd output's error scales with the largest
+# value of its 6x6 patch, not with the output itself, and on heavy-tailed activations (the
+# random-init R-101 of tests/test_gpu_model.py) that perturbation, carried through the losses,
+# tripled the whole-graph gradient error (rms 1.2e-5 vs 4e-6 of the tensor scale; 0.19 % of
+# head.res5.b1.conv2.W beyond 1e-4, against the 0.1 % the parity test allows).  Inference
+# (no gradient) uses it: only the per-op tolerance applies there and it holds with 30x margin.
+WINOGRAD_TRAIN_FORWARD = False
+WINOGRAD_DGRAD = True        # developer switches (error attribution, A/B timing)
+WINOGRAD_WGRAD = True
+WINOGRAD_MIN_MAPS = 64
+WINOGRAD_MAX_MAP = 16
+
+
+def uses_winograd(d):
+    return (USE_WINOGRAD and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1
+            and d.N >= WINOGRAD_MIN_MAPS and max(d.H, d.W) <= WINOGRAD_MAX_MAP)
+
+
+def _wino_ws(d, device, tag='wino'):
+    return _lib.workspace(_lib.load().mrcnn_conv3x3_wino_workspace_bytes(ctx_desc(d)), device, tag)
+
+
+def wino_fwd(x, Wc, d, scale, shift, relu, keep_v=False):
+    """y = relu?(affine?(conv3x3(x))) and, with ``keep_v``, the transformed input (36, tiles, C)
+    for the weight gradient."""
+    flags = (EPI_AFFINE if scale is not None else 0) | (EPI_RELU if relu else 0)
+    y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
+    v = None
+    if keep_v:
+        v = torch.empty((_lib.load().mrcnn_conv3x3_wino_v_bytes(ctx_desc(d)) // 4,),
+                        dtype=torch.float32, device=x.device)
+    _lib.call('mrcnn_conv3x3_wino_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(scale),
+              _lib.ptr(shift), _lib.ptr(y), flags, _lib.ptr(v), _lib.ptr(_wino_ws(d, x.device)),
+              _lib.stream_ptr())
+    return y, v
+
+
+def wino_dgrad(d, g, Wc, fold_scale=None, out_scale=None, out_mask_y=None):
+    gx = empty_nhwc((d.N, d.C, d.H, d.W), g.device)
+    _lib.call('mrcnn_conv3x3_wino_dgrad', ctx_desc(d), _lib.ptr(g), _lib.ptr(Wc),
+              _lib.ptr(fold_scale), _lib.ptr(gx), _lib.ptr(out_scale), _lib.ptr(out_mask_y),
+              _lib.ptr(_wino_ws(d, g.device)), _lib.stream_ptr())
+    return gx
+
+
+def wino_wgrad_into(d, x, v, g, gW, row_scale=None, tag='wino'):
+    """gW = backward-filter from ``g`` and exactly one of ``x`` (raw input) / ``v`` (the
+    transformed input a forward with ``keep_v`` returned)."""
+    _lib.call('mrcnn_conv3x3_wino_wgrad', ctx_desc(d), _lib.ptr(x), _lib.ptr(v), _lib.ptr(g),
+              _lib.ptr(gW), _lib.ptr(row_scale), _lib.ptr(_wino_ws(d, g.device, tag)),
+              _lib.stream_ptr())
 
 
 # ---- weight-gradient side stream -----------------------------------------------------------
@@ -403,11 +466,29 @@ def defer_stream(device):
 def run_deferred_wgrads(jobs):
     """Launch the held-back weight gradients on the current stream (the caller selects it)."""
     for d, x, g, gW, mask_y, in_scale, row_scale in jobs:
+        if mask_y is _WINO:
+            wino_wgrad_into(d, x, in_scale, g, gW, row_scale, tag='wino-defer')
+            continue
         ws = _lib.workspace(_lib.load().mrcnn_conv2d_wgrad_workspace_bytes(ctx_desc(d)),
                             g.device, 'wgrad-defer')
         _lib.call('mrcnn_conv2d_wgrad_ex', ctx_desc(d), _lib.ptr(x), _lib.ptr(g), _lib.ptr(gW),
                   _lib.ptr(ws), _lib.ptr(mask_y), _lib.ptr(in_scale), _lib.ptr(row_scale),
                   _lib.stream_ptr())
+
+
+_WINO = object()       # marker in the mask_y slot of a deferred job: Winograd weight gradient
+
+
+def _wino_wgrad(d, x, v, g, W, row_scale=None):
+    """Weight gradient on the Winograd route from the raw input ``x`` or the kept transformed
+    input ``v`` (the other is None); same gradient-ownership rules as _wgrad_raw."""
+    direct = _direct_grad(W)
+    if direct and _DEFER is not None and id(W) in _DEFER.ids:
+        _DEFER.jobs.append((d, x, g, W.grad, _WINO, v, row_scale))    # v rides in the in_scale slot
+        return None
+    gW = W.grad if direct else empty_nhwc(tuple(W.shape), g.device)
+    wino_wgrad_into(d, x, v, g, gW, row_scale)
+    return None if direct else gW
 
 
 def _wgrad_raw(d, x, g, W, mask_y, in_scale, side=None, row_scale=None):
@@ -533,7 +614,7 @@ class _StageFn(torch.autograd.Function):
         (+ W4,s4,b4 when proj[i])."""
         _lib.require_device(x, params[0])
         x = nhwc(x)
-        blocks, saved, pos = [], [x], 0
+        blocks, saved, pos, wino_v = [], [x], 0, []
         h = x
         for stride, pj in zip(strides, proj):
             n = 12 if pj else 9
@@ -542,7 +623,14 @@ class _StageFn(torch.autograd.Function):
             d1 = make_desc(h.shape, W1.shape, stride, 0)
             h1 = _fwd_raw(h, nhwc(W1), d1, s1, b1, None, True)
             d2 = make_desc(h1.shape, W2.shape, 1, 1)
-            h2 = _fwd_raw(h1, nhwc(W2), d2, s2, b2, None, True)
+            v2 = None
+            training = any(ctx.needs_input_grad)
+            if uses_winograd(d2) and (WINOGRAD_TRAIN_FORWARD or not training):
+                # (with a weight gradient to come, the transformed input is kept for it)
+                h2, v2 = wino_fwd(h1, nhwc(W2), d2, s2, b2, True,
+                                  keep_v=bool(ctx.needs_input_grad[4 + pos + 3]))
+            else:
+                h2 = _fwd_raw(h1, nhwc(W2), d2, s2, b2, None, True)
             d4 = None
             if pj:
                 d4 = make_desc(h.shape, W4.shape, stride, 0)
@@ -553,12 +641,15 @@ class _StageFn(torch.autograd.Function):
             y = _fwd_raw(h2, nhwc(W3), d3, s3, b3, shortcut, True)
             blocks.append(((d1, d2, d3, d4), (W1, W2, W3, W4), pos))
             saved += [h1, h2, y, s1, s2, s3] + ([s4] if pj else [])
+            wino_v.append(v2)
             pos += n
             h = y
         ctx.blocks = blocks
         ctx.proj = tuple(proj)
         ctx.poll = poll
-        ctx.save_for_backward(*saved)
+        ctx.n_saved = len(saved)
+        ctx.wino_slots = [i for i, v in enumerate(wino_v) if v is not None]
+        ctx.save_for_backward(*(saved + [wino_v[i] for i in ctx.wino_slots]))
         ctx.wT = None
         if PRETRANSPOSE_FILTERS and any(ctx.needs_input_grad):
             # The backward's forward-form dgrads need every filter flipped and transposed
@@ -579,6 +670,8 @@ class _StageFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         saved = list(ctx.saved_tensors)
+        wino_v = dict(zip(ctx.wino_slots, saved[ctx.n_saved:]))
+        saved = saved[:ctx.n_saved]
         ng = ctx.needs_input_grad
         grads = [None] * len(ng)
         poll = ctx.poll
@@ -626,10 +719,22 @@ class _StageFn(torch.autograd.Function):
                 grads[base + 9] = _wgrad_raw(d4, x, gm, W4, None, None, side, row_scale=s4)
             gh2 = _dgrad_raw(d3, gm, nhwc(W3), None, None, fold_scale=s3,
                              out_mask_y=h2, out_scale=s2, wT=wT.get('3'))
-            if ng[base + 3]:
-                grads[base + 3] = _wgrad_raw(d2, h1, gh2, W2, None, None, side)
-            gh1 = _dgrad_raw(d2, gh2, nhwc(W2), None, None, out_mask_y=h1, out_scale=s1,
-                             wT=wT.get('2'))
+            if uses_winograd(d2):
+                if ng[base + 3]:
+                    if WINOGRAD_WGRAD:
+                        v2 = wino_v.get(i)
+                        grads[base + 3] = _wino_wgrad(d2, h1 if v2 is None else None, v2, gh2, W2)
+                    else:
+                        grads[base + 3] = _wgrad_raw(d2, h1, gh2, W2, None, None, side)
+                if WINOGRAD_DGRAD:
+                    gh1 = wino_dgrad(d2, gh2, nhwc(W2), out_scale=s1, out_mask_y=h1)
+                else:
+                    gh1 = _dgrad_raw(d2, gh2, nhwc(W2), None, None, out_mask_y=h1, out_scale=s1)
+            else:
+                if ng[base + 3]:
+                    grads[base + 3] = _wgrad_raw(d2, h1, gh2, W2, None, None, side)
+                gh1 = _dgrad_raw(d2, gh2, nhwc(W2), None, None, out_mask_y=h1, out_scale=s1,
+                                 wT=wT.get('2'))
             if ng[base]:
                 grads[base] = _wgrad_raw(d1, x, gh1, W1, None, None, side)
             if poll is not None:

@@ -209,6 +209,32 @@ int mrcnn_conv2d_dgrad_ex(const mrcnn_conv_desc *d, const float *gy, const float
 int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float *gy,
                           float *gw, void *ws, const float *mask_y, const float *in_scale,
                           const float *out_row_scale, void *stream);
+/* Winograd F(4x4,3x3) path (csrc/conv_winograd.h) for 3x3 / stride 1 / pad 1 convolutions —
+ * the algorithm cuDNN selects for the same layers in the reference (chainer autotune off:
+ * cudnnGetConvolutionForwardAlgorithm; call sites as mrcnn_conv2d_fwd).  A third of the MFMA
+ * work of the direct form on the RoI head's 7x7 maps.  Interpolation points 0, +-1, 1/2, -2:
+ * fp32 error max 3.4e-6 / rms 3.7e-7 of the tensor scale against an fp64 direct convolution
+ * (direct fp32: 3.5e-7 / 5.7e-8), inside the 1e-4 parity tolerance.
+ *   fwd:   y = epi(conv(x, w)), epi_flags in {MRCNN_EPI_AFFINE, MRCNN_EPI_RELU}.  v: NULL or a
+ *          buffer of mrcnn_conv3x3_wino_v_bytes(d) that receives the transformed input
+ *          (36 x tiles x C), which mrcnn_conv3x3_wino_wgrad consumes.
+ *   dgrad: gx = (dgrad(gy * w_row_scale[k]) * out_scale[c]) masked by (out_mask_y > 0)
+ *          (any of the three may be NULL; same meaning as in mrcnn_conv2d_dgrad_wt).
+ *   wgrad: gw (K,3,3,C) from gy and exactly one of x (the raw input, transformed into the
+ *          scratch) and v (the forward's kept transform); out_row_scale[k] (or NULL)
+ *          multiplies gw's rows.
+ * ws: scratch of mrcnn_conv3x3_wino_workspace_bytes(d), private to the stream. */
+int64_t mrcnn_conv3x3_wino_v_bytes(const mrcnn_conv_desc *d);
+int64_t mrcnn_conv3x3_wino_workspace_bytes(const mrcnn_conv_desc *d);
+int mrcnn_conv3x3_wino_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
+                           const float *scale, const float *shift, float *y, int epi_flags,
+                           float *v, void *ws, void *stream);
+int mrcnn_conv3x3_wino_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w,
+                             const float *w_row_scale, float *gx, const float *out_scale,
+                             const float *out_mask_y, void *ws, void *stream);
+int mrcnn_conv3x3_wino_wgrad(const mrcnn_conv_desc *d, const float *x, const float *v,
+                             const float *gy, float *gw, const float *out_row_scale, void *ws,
+                             void *stream);
 /* Stride-1 dgrad expressed as a forward-form convolution of gy with the flipped, transposed
  * filter wT[c][R-1-r][S-1-s][k] = w[k][r][s][c] * row_scale[k] (both GEMM operands
  * K-contiguous).  mrcnn_filter_flip_transpose builds wT (C,R,S,K) from w (K,R,S,C)

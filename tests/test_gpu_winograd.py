@@ -1,0 +1,142 @@
+"""Winograd F(4x4,3x3) path (csrc/conv_winograd.h, entry points mrcnn_conv3x3_wino_*) against
+the NumPy oracle's direct convolution evaluated in float64 on the same fp32 inputs.  Same
+per-element criterion as the direct kernels (tests/test_gpu_conv.py): |got - ref| <= 1e-4 |ref|
++ 1e-5 max|ref| — north_star's 1e-4 relative tolerance for fp32 convolutions.  Also pins the
+measured error level (max error <= 1e-5 of the tensor scale) so that a regression of the
+transform constants or of the interpolation points shows up long before the parity bound."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ref
+from chainer_mask_rcnn_amd import _lib
+from chainer_mask_rcnn_amd.functions import conv as C
+from chainer_mask_rcnn_amd.functions._layout import nhwc
+from test_gpu_conv import _close, _64, _t
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, C, H, W, K
+    (256, 128, 7, 7, 128),       # the RoI head's shape class: 2x2 tiles per map, 128x128 GEMM tiles
+    (70, 64, 7, 7, 96),          # tile count not a multiple of the GEMM tile
+    (33, 36, 5, 9, 40),          # channels not multiples of 32, ragged maps (2x3 tiles)
+    (9, 64, 12, 16, 64),         # maps that are whole tiles; 64x64 GEMM tiles
+    (3, 32, 10, 13, 48),         # few maps, ragged
+]
+
+
+def _max_rel_to_scale(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return np.abs(np.asarray(got, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_winograd_fwd_dgrad_wgrad(dev, case):
+    N, Cc, H, W, K = case
+    rng = np.random.RandomState(11)
+    x = np.maximum(rng.standard_normal((N, Cc, H, W)), 0).astype(np.float32)
+    Wt = (rng.standard_normal((K, Cc, 3, 3)) / np.sqrt(9. * Cc)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = (0.3 * rng.standard_normal(K)).astype(np.float32)
+    xt, wt = nhwc(_t(x, dev)), nhwc(_t(Wt, dev))
+    d = C.make_desc(xt.shape, wt.shape, 1, 1)
+
+    # forward with the fused affine + ReLU, transformed input kept
+    y, v = C.wino_fwd(xt, wt, d, _t(sc, dev), _t(sh, dev), True, keep_v=True)
+    pre = np_ref.conv2d_fwd(*_64(x, Wt), None, 1, 1) * sc[None, :, None, None] + sh[None, :, None, None]
+    y_ref = np.maximum(pre, 0)
+    _close(y.cpu().numpy(), y_ref)
+    assert _max_rel_to_scale(y.cpu().numpy(), y_ref) < 1e-5
+    # plain forward (no epilogue, scratch v)
+    y0, _ = C.wino_fwd(xt, wt, d, None, None, False)
+    _close(y0.cpu().numpy(), np_ref.conv2d_fwd(*_64(x, Wt), None, 1, 1))
+
+    # backward-data: gx = (dgrad(g * rs[k]) * os[c]) masked by (m > 0)
+    g = (rng.standard_normal((N, K, H, W)) * (rng.random_sample((N, K, H, W)) < 0.6)).astype(np.float32)
+    rs = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    os_ = rng.uniform(0.5, 1.5, Cc).astype(np.float32)
+    m = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
+    gt = nhwc(_t(g, dev))
+    gx = C.wino_dgrad(d, gt, wt, fold_scale=_t(rs, dev), out_scale=_t(os_, dev),
+                      out_mask_y=nhwc(_t(m, dev)))
+    gx_ref, gW_ref, _ = np_ref.conv2d_bwd(*_64(x, Wt, g * rs[None, :, None, None]), 1, 1)
+    _close(gx.cpu().numpy(), gx_ref * os_[None, :, None, None] * (m > 0))
+    gx1 = C.wino_dgrad(d, gt, wt)
+    gx1_ref, gW1_ref, _ = np_ref.conv2d_bwd(*_64(x, Wt, g), 1, 1)
+    _close(gx1.cpu().numpy(), gx1_ref)
+    assert _max_rel_to_scale(gx1.cpu().numpy(), gx1_ref) < 1e-5
+
+    # backward-filter from the kept transformed input, with and without the row scale
+    gW = torch.empty_like(wt)
+    C.wino_wgrad_into(d, None, v, gt, gW)
+    _close(gW.cpu().numpy(), gW1_ref)
+    assert _max_rel_to_scale(gW.cpu().numpy(), gW1_ref) < 1e-5
+    C.wino_wgrad_into(d, None, v, gt, gW, row_scale=_t(rs, dev))
+    _close(gW.cpu().numpy(), gW_ref)
+    # ... and from the raw input (the train step's route: its forward is the direct kernel)
+    gW2 = torch.empty_like(wt)
+    C.wino_wgrad_into(d, xt, None, gt, gW2, row_scale=_t(rs, dev))
+    assert torch.equal(gW2, gW)
+    with pytest.raises(_lib.MrcnnHipError):
+        C.wino_wgrad_into(d, xt, v, gt, gW2)
+
+
+def test_winograd_is_deterministic(dev):
+    """Ordered slab sums: two runs give bit-identical gradients."""
+    N, Cc, H, W, K = 300, 64, 7, 7, 64
+    rng = np.random.RandomState(3)
+    xt = nhwc(_t(rng.standard_normal((N, Cc, H, W)).astype(np.float32), dev))
+    wt = nhwc(_t((rng.standard_normal((K, Cc, 3, 3)) / 24.).astype(np.float32), dev))
+    gt = nhwc(_t(rng.standard_normal((N, K, H, W)).astype(np.float32), dev))
+    d = C.make_desc(xt.shape, wt.shape, 1, 1)
+    outs = []
+    for _ in range(2):
+        y, v = C.wino_fwd(xt, wt, d, None, None, False, keep_v=True)
+        gW = torch.empty_like(wt)
+        C.wino_wgrad_into(d, None, v, gt, gW)
+        outs.append((y.clone(), C.wino_dgrad(d, gt, wt).clone(), gW.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_winograd_rejects_other_filters(dev):
+    xt = nhwc(torch.zeros((2, 8, 7, 7), device=dev))
+    wt = nhwc(torch.zeros((8, 8, 1, 1), device=dev))
+    d = C.make_desc(xt.shape, wt.shape, 1, 0)
+    with pytest.raises(_lib.MrcnnHipError):
+        C.wino_fwd(xt, wt, d, None, None, False)
+
+
+def test_stage_with_winograd_matches_direct(dev):
+    """A res5-like stage over many 7x7 maps: forward and every gradient of the Winograd route
+    against the implicit-GEMM route of the same fused stage (both fp32; per-element 1e-4)."""
+    from chainer_mask_rcnn_amd.models.resnet_extractor import BuildingBlock
+    torch.manual_seed(0)
+    stage = BuildingBlock(2, 64, 32, 128, 1).to(dev)
+    with torch.no_grad():
+        for name, p in stage.named_parameters():
+            if '.bn' in name and name.endswith('.W'):
+                p.uniform_(0.5, 1.5)
+            elif '.bn' in name:
+                p.normal_(0, 0.3)
+    x = torch.randn(96, 64, 7, 7, device=dev).relu_()
+    gy = None
+    res = {}
+    for use in (False, True):
+        C.USE_WINOGRAD = C.WINOGRAD_TRAIN_FORWARD = use
+        try:
+            xi = x.clone().requires_grad_(True)
+            for p in stage.parameters():
+                p.grad = None
+            y = stage(xi)
+            if gy is None:
+                gy = torch.randn_like(y)
+            y.backward(gy)
+            res[use] = [y.detach().cpu().numpy(), xi.grad.cpu().numpy()] + \
+                [p.grad.cpu().numpy() for _, p in stage.named_parameters() if p.grad is not None]
+        finally:
+            C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD = True, False
+    assert len(res[True]) == len(res[False]) > 4
+    for a, b in zip(res[True], res[False]):
+        _close(a, b, rel=1e-4, floor=2e-5)

@@ -45,19 +45,31 @@ def run(n_layers):
                                  cat(g_labels, torch.int32), cat(g_masks, torch.int32))
         sum(parts).backward()
         grads[dtype] = {n: P[n].grad for n, _ in model.named_parameters() if P[n].grad is not None}
+    def stats(got, ref):
+        got, ref = got.detach().cpu().double(), ref.detach().double()
+        err = ((got - ref).abs() / ref.abs().max().clamp_min(1e-12)).flatten()
+        k = max(1, int(err.numel() * 0.999))
+        return float(err.max()), float(err.kthvalue(k).values), float((err > 1e-4).double().mean()), \
+            float(err.pow(2).mean().sqrt())
     rows = []
     for name, p in model.named_parameters():
         if name.startswith('extractor.conv1') or name.startswith('extractor.bn1') \
                 or name.startswith('extractor.res2') or '.bn' in name:
             continue
         g64 = grads[torch.float64][name]
-        rows.append((name, _rel(p.grad, g64), _rel(grads[torch.float32][name], g64)))
-    rows.sort(key=lambda r: -r[1])
-    print('R-%d: worst HIP %.2e, worst CPU-fp32 %.2e' % (n_layers, max(r[1] for r in rows), max(r[2] for r in rows)))
-    for r in rows[:12]:
-        print('  %-36s hip %.2e  cpu32 %.2e' % r)
+        rows.append((name,) + stats(p.grad, g64) + stats(grads[torch.float32][name], g64))
+    rows.sort(key=lambda r: -r[3])
+    print('R-%d: worst HIP max %.2e frac %.2e, worst CPU-fp32 max %.2e frac %.2e' % (
+        n_layers, max(r[1] for r in rows), max(r[3] for r in rows), max(r[5] for r in rows),
+        max(r[7] for r in rows)))
+    for r in rows[:4]:
+        print('  %-34s hip max %.1e p99.9 %.1e frac %.1e rms %.1e | cpu32 max %.1e p99.9 %.1e frac %.1e rms %.1e' % r)
 
 
 if __name__ == '__main__':
-    for n in (50, 101):
-        run(n)
+    from chainer_mask_rcnn_amd.functions import conv as C
+    for use, fw in ((False, False), (True, False), (True, True)):
+        C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD = use, fw
+        print('Winograd backward:', use, ' Winograd train forward:', fw)
+        for n in (50, 101):
+            run(n)
