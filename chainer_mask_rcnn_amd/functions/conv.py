@@ -603,6 +603,11 @@ SMALL_WGRAD_MAX_PIXELS = 40000
 PRETRANSPOSE_FILTERS = False
 
 
+# set by building_block() around _StageFn.apply: inside forward() grad mode is always off and
+# ctx.needs_input_grad reports the inputs' requires_grad flags even under torch.no_grad()
+_STAGE_RECORDS_GRAPH = True
+
+
 class _StageFn(torch.autograd.Function):
 
     @staticmethod
@@ -624,7 +629,7 @@ class _StageFn(torch.autograd.Function):
             h1 = _fwd_raw(h, nhwc(W1), d1, s1, b1, None, True)
             d2 = make_desc(h1.shape, W2.shape, 1, 1)
             v2 = None
-            training = any(ctx.needs_input_grad)
+            training = _STAGE_RECORDS_GRAPH and any(ctx.needs_input_grad)
             if uses_winograd(d2) and (WINOGRAD_TRAIN_FORWARD or not training):
                 # (with a weight gradient to come, the transformed input is kept for it)
                 h2, v2 = wino_fwd(h1, nhwc(W2), d2, s2, b2, True,
@@ -768,4 +773,9 @@ def building_block(x, blocks, first_stride=None, poll=None):
                    b.conv3.W, b.bn3.W, b.bn3.b]
         if b.projection:
             params += [b.conv4.W, b.bn4.W, b.bn4.b]
-    return _StageFn.apply(x, tuple(strides), tuple(proj), poll, *params)
+    global _STAGE_RECORDS_GRAPH
+    _STAGE_RECORDS_GRAPH = torch.is_grad_enabled()
+    try:
+        return _StageFn.apply(x, tuple(strides), tuple(proj), poll, *params)
+    finally:
+        _STAGE_RECORDS_GRAPH = True
