@@ -148,7 +148,8 @@ __global__ void __launch_bounds__(256) wino_data_transform_kernel(
 }
 
 // ---- output transform + epilogue: one thread = one tile x two channels ------------------------
-//   y = A^T m A;  y = y * scale[k] + shift[k] (AFFINE);  relu (RELU);  y = mask > 0 ? y : 0
+//   y = A^T m A;  y = y * scale[k] + shift[k] (AFFINE) or y += shift[k] (BIAS);  relu (RELU);
+//   y = mask > 0 ? y : 0
 struct WinoOutParams {
     const float *m;
     float *y;
@@ -200,9 +201,10 @@ __global__ void __launch_bounds__(256) wino_output_transform_kernel(const WinoOu
         for (int i = 0; i < 4; ++i) s[i][b] = o[i];
     }
     F2 sc = {1.f, 1.f}, sh = {0.f, 0.f};
-    const bool aff = (p.flags & MRCNN_EPI_AFFINE) != 0, relu = (p.flags & MRCNN_EPI_RELU) != 0;
+    const bool aff = (p.flags & (MRCNN_EPI_AFFINE | MRCNN_EPI_BIAS)) != 0;
+    const bool relu = (p.flags & MRCNN_EPI_RELU) != 0;
     if (aff) {
-        sc = *reinterpret_cast<const F2 *>(p.scale + k);
+        if (p.scale) sc = *reinterpret_cast<const F2 *>(p.scale + k);
         if (p.shift) sh = *reinterpret_cast<const F2 *>(p.shift + k);
     }
 #pragma unroll
@@ -396,9 +398,11 @@ extern "C" int mrcnn_conv3x3_wino_fwd(const mrcnn_conv_desc *d, const float *x, 
 {
     if (int rc = wino_check(d, "conv3x3_wino_fwd")) return rc;
     MRCNN_REQUIRE(x && w && y && ws, "conv3x3_wino_fwd: null pointer");
-    MRCNN_REQUIRE((epi_flags & ~(MRCNN_EPI_AFFINE | MRCNN_EPI_RELU)) == 0,
-                  "conv3x3_wino_fwd: only AFFINE / RELU epilogues");
+    MRCNN_REQUIRE((epi_flags & ~(MRCNN_EPI_AFFINE | MRCNN_EPI_BIAS | MRCNN_EPI_RELU)) == 0,
+                  "conv3x3_wino_fwd: only AFFINE or BIAS, and RELU epilogues");
     MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_AFFINE) || scale, "conv3x3_wino_fwd: affine flag without scale");
+    MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_BIAS) || (shift && !scale && !(epi_flags & MRCNN_EPI_AFFINE)),
+                  "conv3x3_wino_fwd: the bias flag takes the bias in `shift` and excludes AFFINE");
     hipStream_t s = mrcnn::as_stream(stream);
     const WinoGeom g = wino_geom(d);
     float *u = (float *)ws;

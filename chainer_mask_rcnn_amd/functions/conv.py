@@ -65,6 +65,9 @@ def epilogue_bwd(gy, y=None, scale=None):
     return g
 
 
+_CONV_RECORDS_GRAPH = True
+
+
 class _Conv2dFn(torch.autograd.Function):
     """y = relu?( affine?( conv(x, W) + b? ) + residual? )"""
 
@@ -84,10 +87,14 @@ class _Conv2dFn(torch.autograd.Function):
             flags |= EPI_RESIDUAL
         if relu:
             flags |= EPI_RELU
-        y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
-        _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(b),
-                  _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(y), flags,
-                  _lib.ptr(split_ws(x.device)), _lib.stream_ptr())
+        ctx.wino = uses_winograd(d) and residual is None and (b is None or scale is None)
+        if ctx.wino and (WINOGRAD_TRAIN_FORWARD or not (_CONV_RECORDS_GRAPH and any(ctx.needs_input_grad))):
+            y, _ = wino_fwd(x, Wc, d, scale, shift if scale is not None else b, relu)
+        else:
+            y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
+            _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(b),
+                      _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(y), flags,
+                      _lib.ptr(split_ws(x.device)), _lib.stream_ptr())
         ctx.d = d
         ctx.relu = relu
         ctx.has_bias = b is not None
@@ -111,7 +118,9 @@ class _Conv2dFn(torch.autograd.Function):
         gx = gW = gb = None
         if need_w:
             W = ctx.W_param
-            if USE_WGRAD_STREAM:
+            if ctx.wino and WINOGRAD_WGRAD:
+                gW = _wino_wgrad(d, x, None, g, W)
+            elif USE_WGRAD_STREAM:
                 gW = _wgrad_raw(d, x, g, W, None, None, wgrad_stream(gy.device))
             else:
                 direct = _direct_grad(W)
@@ -127,7 +136,8 @@ class _Conv2dFn(torch.autograd.Function):
                           _lib.ptr(gWt), _lib.ptr(ws), _lib.stream_ptr())
                 gW = None if direct else gWt
         if need_x:
-            gx = _dgrad_raw(d, g, Wc, None, None)
+            gx = wino_dgrad(d, g, Wc) if ctx.wino and WINOGRAD_DGRAD else \
+                _dgrad_raw(d, g, Wc, None, None)
         if need_b:
             b = ctx.b_param
             direct = _direct_grad(b)
@@ -150,7 +160,12 @@ def conv2d(x, W, b=None, stride=1, pad=0, scale=None, shift=None, residual=None,
     produced for them — the reference computes but never uses it,
     examples/train_common.py:188-190).
     """
-    return _Conv2dFn.apply(x, W, b, scale, shift, residual, stride, pad, relu)
+    global _CONV_RECORDS_GRAPH
+    _CONV_RECORDS_GRAPH = torch.is_grad_enabled()     # see _STAGE_RECORDS_GRAPH
+    try:
+        return _Conv2dFn.apply(x, W, b, scale, shift, residual, stride, pad, relu)
+    finally:
+        _CONV_RECORDS_GRAPH = True
 
 
 class _StemFn(torch.autograd.Function):
@@ -354,6 +369,13 @@ def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, acc
 # the implicit-GEMM kernel.  fp32 throughout; error 3.4e-6 of the tensor scale (direct: 3.5e-7),
 # parity tolerance 1e-4.
 USE_WINOGRAD = True
+# Which layers: 3x3 / stride 1 / pad 1 with enough work per frequency plane for the 36 batched
+# GEMMs to fill the GPU — the RoI head's res5 (1024 maps of 7x7, 512 -> 512), the RPN's conv1
+# (1024 -> 1024) and, at inference batch sizes, res4 (256 -> 256).  Narrow layers (C < 256) and
+# the two-image res4 maps of a train step stay on the implicit-GEMM kernel: their GEMMs would
+# be 2-8 K slices deep and the transform passes would cost what the MFMAs save.
+WINOGRAD_MIN_CHANNELS = 256
+WINOGRAD_MIN_WORK = 1 << 27          # tiles x C x K
 # Which passes take the Winograd route.  Backward-data and backward-filter always do: their
 # extra rounding (3e-6 of the gradient tensor's scale) is invisible next to the fp32 floor of
 # the whole-graph gradients (tools/grad_floor.py: identical per-layer errors with and without).
@@ -366,13 +388,13 @@ USE_WINOGRAD = True
 WINOGRAD_TRAIN_FORWARD = False
 WINOGRAD_DGRAD = True        # developer switches (error attribution, A/B timing)
 WINOGRAD_WGRAD = True
-WINOGRAD_MIN_MAPS = 64
-WINOGRAD_MAX_MAP = 16
 
 
 def uses_winograd(d):
-    return (USE_WINOGRAD and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1
-            and d.N >= WINOGRAD_MIN_MAPS and max(d.H, d.W) <= WINOGRAD_MAX_MAP)
+    if not (USE_WINOGRAD and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1):
+        return False
+    tiles = d.N * ((d.H + 3) // 4) * ((d.W + 3) // 4)
+    return min(d.C, d.K) >= WINOGRAD_MIN_CHANNELS and tiles * d.C * d.K >= WINOGRAD_MIN_WORK
 
 
 def _wino_ws(d, device, tag='wino'):
@@ -380,9 +402,10 @@ def _wino_ws(d, device, tag='wino'):
 
 
 def wino_fwd(x, Wc, d, scale, shift, relu, keep_v=False):
-    """y = relu?(affine?(conv3x3(x))) and, with ``keep_v``, the transformed input (36, tiles, C)
-    for the weight gradient."""
-    flags = (EPI_AFFINE if scale is not None else 0) | (EPI_RELU if relu else 0)
+    """y = relu?(affine?(conv3x3(x))) — ``scale`` None with a ``shift``: plain bias — and, with
+    ``keep_v``, the transformed input (36, tiles, C) for the weight gradient."""
+    flags = (EPI_AFFINE if scale is not None else (EPI_BIAS if shift is not None else 0)) \
+        | (EPI_RELU if relu else 0)
     y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
     v = None
     if keep_v:

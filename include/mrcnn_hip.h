@@ -215,7 +215,8 @@ int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float 
  * work of the direct form on the RoI head's 7x7 maps.  Interpolation points 0, +-1, 1/2, -2:
  * fp32 error max 3.4e-6 / rms 3.7e-7 of the tensor scale against an fp64 direct convolution
  * (direct fp32: 3.5e-7 / 5.7e-8), inside the 1e-4 parity tolerance.
- *   fwd:   y = epi(conv(x, w)), epi_flags in {MRCNN_EPI_AFFINE, MRCNN_EPI_RELU}.  v: NULL or a
+ *   fwd:   y = epi(conv(x, w)), epi_flags: MRCNN_EPI_AFFINE (scale, shift) or MRCNN_EPI_BIAS
+ *          (the bias in `shift`, scale NULL), and MRCNN_EPI_RELU.  v: NULL or a
  *          buffer of mrcnn_conv3x3_wino_v_bytes(d) that receives the transformed input
  *          (36 x tiles x C), which mrcnn_conv3x3_wino_wgrad consumes.
  *   dgrad: gx = (dgrad(gy * w_row_scale[k]) * out_scale[c]) masked by (out_mask_y > 0)

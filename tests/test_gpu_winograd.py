@@ -123,6 +123,8 @@ def test_stage_with_winograd_matches_direct(dev):
     x = torch.randn(96, 64, 7, 7, device=dev).relu_()
     gy = None
     res = {}
+    saved = (C.WINOGRAD_MIN_CHANNELS, C.WINOGRAD_MIN_WORK)
+    C.WINOGRAD_MIN_CHANNELS, C.WINOGRAD_MIN_WORK = 1, 0      # route this narrow stage too
     for use in (False, True):
         C.USE_WINOGRAD = C.WINOGRAD_TRAIN_FORWARD = use
         try:
@@ -137,6 +139,51 @@ def test_stage_with_winograd_matches_direct(dev):
                 [p.grad.cpu().numpy() for _, p in stage.named_parameters() if p.grad is not None]
         finally:
             C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD = True, False
+    C.WINOGRAD_MIN_CHANNELS, C.WINOGRAD_MIN_WORK = saved
     assert len(res[True]) == len(res[False]) > 4
     for a, b in zip(res[True], res[False]):
         _close(a, b, rel=1e-4, floor=2e-5)
+
+
+@pytest.mark.parametrize('train_forward', [False, True])
+def test_conv2d_winograd_route_bias_relu(dev, train_forward):
+    """F.conv2d on an RPN-conv1-like layer (3x3, bias, ReLU; wide enough to be routed): forward,
+    input / filter / bias gradients against the float64 oracle.  In a train step only the
+    backward takes the Winograd route (WINOGRAD_TRAIN_FORWARD); under no_grad the forward does."""
+    from chainer_mask_rcnn_amd import functions as F
+    N, Cc, H, W, K = 2, 256, 19, 30, 256
+    rng = np.random.RandomState(5)
+    x = np.maximum(rng.standard_normal((N, Cc, H, W)), 0).astype(np.float32)
+    Wt = (rng.standard_normal((K, Cc, 3, 3)) / np.sqrt(9. * Cc)).astype(np.float32)
+    b = (0.2 * rng.standard_normal(K)).astype(np.float32)
+    saved = (C.WINOGRAD_MIN_WORK, C.WINOGRAD_TRAIN_FORWARD)
+    C.WINOGRAD_MIN_WORK, C.WINOGRAD_TRAIN_FORWARD = 0, train_forward
+    calls = {'fwd': 0, 'dgrad': 0, 'wgrad': 0}
+    orig = (C.wino_fwd, C.wino_dgrad, C.wino_wgrad_into)
+
+    def spy(name, fn):
+        def wrapped(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapped
+    C.wino_fwd, C.wino_dgrad, C.wino_wgrad_into = (spy(n, f) for n, f in zip(calls, orig))
+    try:
+        xt, wt, bt = _t(x, dev, True), _t(Wt, dev, True), _t(b, dev, True)
+        y = F.conv2d(xt, wt, bt, stride=1, pad=1, relu=True)
+        pre = np_ref.conv2d_fwd(*_64(x, Wt, b), 1, 1)
+        _close(y.detach().cpu().numpy(), np.maximum(pre, 0))
+        gy = rng.standard_normal(pre.shape).astype(np.float32)
+        y.backward(_t(gy, dev))
+        g = gy * (y.detach().cpu().numpy() > 0)
+        gx, gW, gb = np_ref.conv2d_bwd(*_64(x, Wt, g), 1, 1)
+        _close(xt.grad.cpu().numpy(), gx)
+        _close(wt.grad.cpu().numpy(), gW)
+        _close(bt.grad.cpu().numpy(), gb)
+        assert calls == {'fwd': int(train_forward), 'dgrad': 1, 'wgrad': 1}
+        with torch.no_grad():
+            y2 = F.conv2d(xt, wt, bt, stride=1, pad=1, relu=True)
+        assert calls['fwd'] == int(train_forward) + 1
+        _close(y2.cpu().numpy(), np.maximum(pre, 0))
+    finally:
+        C.wino_fwd, C.wino_dgrad, C.wino_wgrad_into = orig
+        C.WINOGRAD_MIN_WORK, C.WINOGRAD_TRAIN_FORWARD = saved
