@@ -91,9 +91,10 @@ def build_trainer(n_layers, device, world, lr_batch, force_dp=False, bucket_byte
     if defer > 0:
         # hold the weight gradients (+ update) of the first res5 block's 3x3 / 1x1 back into the
         # next step's proposal window, where the GPU is otherwise nearly idle (optimizers.py)
-        a, b1 = model.head.res5.a, model.head.res5.b1
+        a, b1, b2 = model.head.res5.a, model.head.res5.b1, model.head.res5.b2
         opt.defer_weight_gradients([a.conv2.W, a.conv1.W, a.conv3.W, a.conv4.W, b1.conv2.W,
-                                    b1.conv1.W, b1.conv3.W][:defer])
+                                    b1.conv1.W, b1.conv3.W, b2.conv2.W, b2.conv1.W,
+                                    b2.conv3.W][:defer])
     return model, chain, opt, sync
 
 

@@ -374,8 +374,9 @@ USE_WINOGRAD = True
 # (1024 -> 1024) and, at inference batch sizes, res4 (256 -> 256).  Narrow layers (C < 256) and
 # the two-image res4 maps of a train step stay on the implicit-GEMM kernel: their GEMMs would
 # be 2-8 K slices deep and the transform passes would cost what the MFMAs save.
-WINOGRAD_MIN_CHANNELS = 256
-WINOGRAD_MIN_WORK = 1 << 27          # tiles x C x K
+import os as _os
+WINOGRAD_MIN_CHANNELS = int(_os.environ.get('MRCNN_WINO_MIN_CH', 256))
+WINOGRAD_MIN_WORK = int(_os.environ.get('MRCNN_WINO_MIN_WORK', 1 << 27))          # tiles x C x K
 # Which passes take the Winograd route.  Backward-data and backward-filter always do: their
 # extra rounding (3e-6 of the gradient tensor's scale) is invisible next to the fp32 floor of
 # the whole-graph gradients (tools/grad_floor.py: identical per-layer errors with and without).
