@@ -24,4 +24,10 @@ def dev():
     import torch
     if not torch.cuda.is_available():
         pytest.skip('no ROCm device')
+    # The test models are small (64 sampled RoIs, 224x320 images): lower the work threshold of
+    # the Winograd route (a performance heuristic, functions/conv.py:uses_winograd) so that the
+    # model-level parity tests run the SAME route as the full-size configurations — the RoI
+    # head's 3x3 layers and the RPN conv1 on Winograd backward / inference forward.
+    from chainer_mask_rcnn_amd.functions import conv
+    conv.WINOGRAD_MIN_WORK = 1 << 24
     return torch.device('cuda:0')
