@@ -68,8 +68,8 @@ def run(n_layers):
 
 if __name__ == '__main__':
     from chainer_mask_rcnn_amd.functions import conv as C
-    for use, fw in ((True, False), (True, 'conv2d'), (True, 'stage')):
-        C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD = use, fw
-        print('Winograd backward:', use, ' Winograd train forward:', fw)
+    for use, fw, blk in ((True, 'conv2d', ()), (True, 'conv2d', (2,)), (True, 'conv2d', (1,)), (True, 'conv2d', (0,))):
+        C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD, C.WINOGRAD_TRAIN_FORWARD_BLOCKS = use, fw, blk
+        print('Winograd backward:', use, ' Winograd train forward:', fw, blk)
         for n in (101,):
             run(n)
