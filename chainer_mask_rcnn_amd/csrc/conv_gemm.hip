@@ -141,6 +141,16 @@ struct GemmParams {
     const float *res_g, *res_y, *out_mask_y;
     float *split_ws;     // host only: caller's split-K workspace (kSplitWsBytes) or NULL
     unsigned a_bytes, b_bytes, c_bytes;  // buffer extents (bytes) of A (and mask_y), B, C
+    // Fused tail (FWD / DGRAD, gridDim.y == 1): workgroups [0, tail_first) run whole tiles as
+    // usual; the workgroups behind them run the tiles of the LEFTOVER rows — the rows beyond the
+    // last full round of resident workgroups — each cut along K into tail_splits pieces that
+    // write raw partial sums into slabs of tail_ws (summed, in order, by splitk_epilogue_kernel).
+    // Dispatched last, the short pieces fill the CUs as the final round of whole tiles drains,
+    // instead of a separate remainder launch that waits for the main launch to finish.
+    int tail_first, tail_splits, tail_split_len, tail_row0;
+    unsigned tail_bytes;
+    float *tail_ws;
+    int64_t tail_stride;
     // Batched launches (gridDim.z > 1; the 36 per-frequency GEMMs of the Winograd path,
     // winograd.hip): floats between consecutive problems of A, B and C.  The extents above
     // are then per problem.
@@ -260,12 +270,21 @@ conv_gemm_kernel(const GemmParams p)
     // and x — land on one or two XCDs instead of all eight.
     const int ntn = (p.N + BN - 1) / BN;
     int tile = blockIdx.x + blockIdx.y * gridDim.x;
-    {
-        const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+    int split;
+    int split_len = p.split_len;
+    const bool tail = MODE != WGRAD && p.tail_splits > 0 && tile >= p.tail_first;   // uniform
+    if (tail) {
+        const int rem = tile - p.tail_first;
+        split = rem % p.tail_splits;
+        tile = p.tail_first + rem / p.tail_splits;
+        split_len = p.tail_split_len;
+    } else {
+        const int nwg = (MODE != WGRAD && p.tail_splits > 0) ? p.tail_first : (int)(gridDim.x * gridDim.y);
+        const int q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        split = tile / (int)gridDim.x;
+        tile -= split * (int)gridDim.x;
     }
-    const int split = tile / (int)gridDim.x;
-    tile -= split * (int)gridDim.x;
     const int m0 = p.m_lo + (tile / ntn) * BM;
     const int n0 = (tile % ntn) * BN;
 
@@ -373,9 +392,9 @@ conv_gemm_kernel(const GemmParams p)
     }
     int kt0 = 0;
     int nslices = (MODE == WGRAD) ? (k_end - k_begin + BK - 1) / BK : ntaps * cprs;
-    if (MODE != WGRAD && p.split_len > 0) {
-        kt0 = split * p.split_len;
-        nslices = max(0, min(nslices - kt0, p.split_len));
+    if (MODE != WGRAD && split_len > 0) {
+        kt0 = split * split_len;
+        nslices = max(0, min(nslices - kt0, split_len));
     }
 
     float4 ra[AV], rb[BV];
@@ -670,19 +689,23 @@ conv_gemm_kernel(const GemmParams p)
     // ---------------- epilogue ------------------------------------------------------
     // Per 32x32 MFMA tile: compute the 16 element offsets, issue every auxiliary load
     // (residual / accumulate / shortcut gradient) back to back, then combine and store.
-    const float *out_base = p.C + zb * p.batch_c;
-    out_base += (int64_t)split * p.split_stride;
-    const __amdgpu_buffer_rsrc_t rC = make_rsrc(out_base, p.c_bytes);
+    const float *out_base = tail ? p.tail_ws + (int64_t)split * p.tail_stride
+                                 : p.C + zb * p.batch_c + (int64_t)split * p.split_stride;
+    const __amdgpu_buffer_rsrc_t rC = make_rsrc(out_base, tail ? p.tail_bytes : p.c_bytes);
+    const int e_flags = tail ? 0 : p.flags;              // tail pieces store raw partial sums
+    const int e_row0 = tail ? p.tail_row0 : p.out_row0;
+    const int e_ldc = tail ? p.N : p.ldc;
+    const bool slab_rows = MODE != WGRAD && split_len > 0;   // slabs are indexed by GEMM row
     const __amdgpu_buffer_rsrc_t rRes = make_rsrc(p.residual, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rResG = make_rsrc(p.res_g, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rResY = make_rsrc(p.res_y, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rOutM = make_rsrc(p.out_mask_y, p.c_bytes);
-    const bool f_bias = (p.flags & MRCNN_EPI_BIAS) != 0, f_aff = (p.flags & MRCNN_EPI_AFFINE) != 0;
-    const bool f_res = (p.flags & MRCNN_EPI_RESIDUAL) != 0, f_relu = (p.flags & MRCNN_EPI_RELU) != 0;
-    const bool f_acc = (p.flags & MRCNN_EPI_ACCUM) != 0;
-    const bool f_resg = MODE != WGRAD && p.res_g != nullptr;
+    const bool f_bias = (e_flags & MRCNN_EPI_BIAS) != 0, f_aff = (e_flags & MRCNN_EPI_AFFINE) != 0;
+    const bool f_res = (e_flags & MRCNN_EPI_RESIDUAL) != 0, f_relu = (e_flags & MRCNN_EPI_RELU) != 0;
+    const bool f_acc = (e_flags & MRCNN_EPI_ACCUM) != 0;
+    const bool f_resg = MODE != WGRAD && !tail && p.res_g != nullptr;
     const bool f_resy = f_resg && p.res_y != nullptr;
-    const bool f_outm = MODE != WGRAD && p.out_mask_y != nullptr;
+    const bool f_outm = MODE != WGRAD && !tail && p.out_mask_y != nullptr;
     constexpr int EG = 8;       // accumulator rows handled per batch of auxiliary loads
 
     if constexpr (MODE == FWD && TM == 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
@@ -729,11 +752,11 @@ conv_gemm_kernel(const GemmParams p)
                     v[q] = *reinterpret_cast<const float4 *>(ep + r * LDW + c4 * 4);
                     const int row = m0 + wm * (32 * TM) + i * 32 + r;
                     int o;
-                    if (p.perm_n > 0 && p.split_len == 0) {
+                    if (p.perm_n > 0 && !slab_rows) {
                         const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
                         o = pr.n < p.perm_n ? (pr.n * (p.gp * p.gq) + pr.pos) * p.ldc + col : -1;
                     } else {
-                        o = (row - p.out_row0) * p.ldc + col;
+                        o = (row - e_row0) * e_ldc + col;
                     }
                     off[q] = (col_ok && row < p.M && o >= 0) ? 4u * (unsigned)o : kOOB;
                 }
@@ -820,13 +843,13 @@ conv_gemm_kernel(const GemmParams p)
                             o = ((n * p.oh + gy * p.stride) * p.ow + gx * p.stride) * p.ldc + col_off;
                         else
                             o = ((n * (2 * p.gp) + 2 * gy) * (2 * p.gq) + 2 * gx) * p.ko + col_off;
-                    } else if (FWDLIKE && p.perm_n > 0 && p.split_len == 0) {
+                    } else if (FWDLIKE && p.perm_n > 0 && !slab_rows) {
                         // position-major GEMM row -> (image, position) row of the NHWC tensor
                         // (split-K slabs stay indexed by GEMM row; the slab-sum kernel maps)
                         const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
                         o = pr.n < p.perm_n ? (pr.n * (p.gp * p.gq) + pr.pos) * p.ldc + col_off : -1;
                     } else {
-                        o = (row - p.out_row0) * p.ldc + col_off;
+                        o = (row - e_row0) * e_ldc + col_off;
                     }
                     off[q] = (col_ok && row < p.M && o >= 0) ? 4u * (unsigned)o : kOOB;
                 }
@@ -1104,6 +1127,58 @@ void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_s
                        s, f);
 }
 
+int g_fused_tail = 512;            // mrcnn_set_tuning("fused_tail", 0 = off, else target number of tail pieces)
+
+// Rows [0, rows_main) as whole TMxTN tiles and rows [rows_main, p.M) as K-split pieces of the
+// same tile shape in ONE launch (GemmParams::tail_*), then the ordered slab sum.  Returns false
+// (nothing launched) when the problem does not qualify.
+template <int TM, int TN, int MODE>
+bool launch_fused_tail(GemmParams p, int rows_main, hipStream_t s)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    if (!g_fused_tail || !can_split_rows<MODE>(p) || p.split_len != 0 || rows_main <= 0 ||
+        rows_main % BM != 0 || rows_main >= p.M)
+        return false;
+    const int64_t ntn = mrcnn::ceil_div(p.N, BN);
+    const int64_t main_tiles = (rows_main / BM) * ntn;
+    const int rows_left = p.M - rows_main;
+    const int64_t tail_tiles = mrcnn::ceil_div(rows_left, BM) * ntn;
+    const int total_slices = p.R * p.S * (int)mrcnn::ceil_div(p.Kc, BK);
+    int64_t splits = std::min<int64_t>(std::min<int64_t>(16, total_slices / 4),
+                                       mrcnn::ceil_div(g_fused_tail, tail_tiles));
+    while (splits > 1 && (int64_t)rows_left * p.N * splits * 4 > kSplitWsBytes) --splits;
+    if (splits < 2) return false;
+    p.tail_split_len = (int)mrcnn::ceil_div(total_slices, splits);
+    splits = mrcnn::ceil_div(total_slices, p.tail_split_len);
+    p.tail_first = (int)main_tiles;
+    p.tail_splits = (int)splits;
+    p.tail_row0 = rows_main;
+    p.tail_ws = p.split_ws;
+    p.tail_stride = (int64_t)rows_left * p.N;
+    p.tail_bytes = (unsigned)(p.tail_stride * 4);
+    p.m_lo = 0;
+    {
+        const double kdepth = (double)p.R * p.S * (double)p.Kc;
+        const double flops = 2.0 * p.M * p.N * kdepth;
+        const double bytes = 4.0 * ((double)p.M * p.N + (double)p.M * p.Kc + (double)p.N * kdepth);
+        mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
+                                  (TM == 2 ? 0 : 1),
+                              flops, bytes, s);
+        launch_kernel<TM, TN, MODE>(p, main_tiles + tail_tiles * splits, 1, s);
+    }
+    FixParams f = {};
+    f.ws = p.split_ws; f.C = p.C;
+    f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.residual = p.residual;
+    f.res_g = p.res_g; f.res_y = p.res_y; f.out_mask_y = p.out_mask_y;
+    f.splits = (int)splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_main; f.ldc = p.ldc;
+    f.flags = p.flags; f.stride = p.tail_stride;
+    f.perm_n = MODE == FWD ? p.perm_n : 0; f.pq = p.gp * p.gq;
+    const int64_t n = (int64_t)rows_left * (p.N / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0,
+                       s, f);
+    return true;
+}
+
 // The 64x64-tile remainder of a 128x128-tile launch (rows [rows_lo, M)) runs alone on the GPU
 // after the main launch: few workgroups, each walking the whole K.  Cut along K so that about
 // two workgroups per CU share the work.
@@ -1159,6 +1234,7 @@ void launch_small(const GemmParams &p, hipStream_t s)
         launch_tiles<1, 1, MODE>(p, 0, p.M, 1, s);
         return;
     }
+    if (launch_fused_tail<1, 1, MODE>(p, rows_main, s)) return;
     launch_tiles<1, 1, MODE>(p, 0, rows_main, 1, s);
     launch_split_rows<MODE>(p, rows_main, splits, total_slices, s);
 }
@@ -1188,8 +1264,10 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
             }
         }
         const int rows_main = (int)std::min<int64_t>(p.M, main_tiles_m * 128);
-        launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
-        if (rows_main < p.M) launch_remainder<MODE>(p, rows_main, s);
+        if (!(splits == 1 && launch_fused_tail<2, 2, MODE>(p, rows_main, s))) {
+            launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
+            if (rows_main < p.M) launch_remainder<MODE>(p, rows_main, s);
+        }
     }
     return mrcnn::check_launch("conv_gemm");
 }
@@ -1276,6 +1354,10 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "gemm_extra_lds") == 0) {
         g_extra_lds = value;
+        return 0;
+    }
+    if (strcmp(name, "fused_tail") == 0) {
+        g_fused_tail = value == 1 ? 512 : value;
         return 0;
     }
     if (strcmp(name, "small_m_split") == 0) {

@@ -166,7 +166,11 @@ int64_t mrcnn_conv2d_split_workspace_bytes(void);
 /* Developer switches for A/B measurements (results are identical either way):
  *   "position_major_rows" (default 1): forward-form convolutions over many small maps (RoI
  *   features, 3x3 / pad 1 on 7x7) order their GEMM rows position-major so that the K slices of
- *   filter taps that fall into the zero padding for every row of a tile are skipped. */
+ *   filter taps that fall into the zero padding for every row of a tile are skipped.
+ *   "fused_tail" (default 512 = target number of pieces, 0 = off): the rows beyond the last full
+ *   round of resident workgroups run as K-split pieces INSIDE the main launch (dispatched last,
+ *   they fill the CUs while the final round drains) instead of a separate remainder launch;
+ *   summation order of those rows differs between the two settings (both deterministic). */
 int mrcnn_set_tuning(const char *name, int value);
 int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                      const float *bias, const float *scale, const float *shift,
