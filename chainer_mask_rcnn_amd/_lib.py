@@ -66,7 +66,9 @@ SIGNATURES = {
     'mrcnn_conv2d_wgrad_ex': (c_int, [_DP] + [c_vp] * 8),
     'mrcnn_conv3x3_wino_v_bytes': (c_i64, [_DP]),
     'mrcnn_conv3x3_wino_workspace_bytes': (c_i64, [_DP]),
-    'mrcnn_conv3x3_wino_fwd': (c_int, [_DP] + [c_vp] * 5 + [c_int] + [c_vp] * 3),
+    'mrcnn_conv3x3_wino_u_bytes': (c_i64, [_DP]),
+    'mrcnn_conv3x3_wino_filter': (c_int, [_DP] + [c_vp] * 3),
+    'mrcnn_conv3x3_wino_fwd': (c_int, [_DP] + [c_vp] * 6 + [c_int] + [c_vp] * 3),
     'mrcnn_conv3x3_wino_dgrad': (c_int, [_DP] + [c_vp] * 8),
     'mrcnn_conv3x3_wino_wgrad': (c_int, [_DP] + [c_vp] * 7),
     'mrcnn_filter_flip_transpose': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),

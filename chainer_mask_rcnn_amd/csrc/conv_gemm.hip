@@ -1197,6 +1197,7 @@ void launch_remainder(const GemmParams &p, int rows_lo, hipStream_t s)
     launch_split_rows<MODE>(p, rows_lo, (int)splits, total_slices, s);
 }
 
+int g_small_whole_max = 1024, g_small_rem_max = 154;   // developer knobs (A/B)
 int g_small_m_split = 0;          // mrcnn_set_tuning("small_m_split", target workgroups per CU)
 
 template <int MODE>
@@ -1220,8 +1221,8 @@ void launch_small(const GemmParams &p, hipStream_t s)
             return;
         }
     }
-    const bool can_split = can_split_rows<MODE>(p) && whole > 0 && whole <= 1024 && rem > 0 &&
-                           rem < 154 && total_slices >= 8;   // beyond 4 tile-times per CU the
+    const bool can_split = can_split_rows<MODE>(p) && whole > 0 && whole <= g_small_whole_max && rem > 0 &&
+                           rem < g_small_rem_max && total_slices >= 8;   // beyond 4 tile-times per CU the
                                                              // two extra launches cost more than
                                                              // the imbalance
     const int rows_main = can_split ? (int)std::min<int64_t>(p.M, (whole / tn) * 64) : p.M;
@@ -1358,6 +1359,14 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "fused_tail") == 0) {
         g_fused_tail = value == 1 ? 512 : value;
+        return 0;
+    }
+    if (strcmp(name, "small_whole_max") == 0) {
+        g_small_whole_max = value;
+        return 0;
+    }
+    if (strcmp(name, "small_rem_max") == 0) {
+        g_small_rem_max = value;
         return 0;
     }
     if (strcmp(name, "small_m_split") == 0) {

@@ -392,12 +392,31 @@ extern "C" int64_t mrcnn_conv3x3_wino_workspace_bytes(const mrcnn_conv_desc *d)
     return 4 * ((1 + kWinoMaxSplits) * wino_u_floats(d) + 2 * wino_plane_floats(d, (int)ch));
 }
 
+// u_bytes: size of a transformed filter (36 x K x C floats)
+extern "C" int64_t mrcnn_conv3x3_wino_u_bytes(const mrcnn_conv_desc *d)
+{
+    return d ? 4 * wino_u_floats(d) : 0;
+}
+
+// u (36, K, C) = G w G^T of a KRSC filter — what mrcnn_conv3x3_wino_fwd builds per call when it
+// is not handed one (inference: the filter does not change between calls)
+extern "C" int mrcnn_conv3x3_wino_filter(const mrcnn_conv_desc *d, const float *w, float *u,
+                                         void *stream)
+{
+    if (int rc = wino_check(d, "conv3x3_wino_filter")) return rc;
+    MRCNN_REQUIRE(w && u, "conv3x3_wino_filter: null pointer");
+    hipLaunchKernelGGL((wino_filter_transform_kernel<false>),
+                       dim3((d->C + 31) / 32, (d->K + 31) / 32), dim3(256), 0,
+                       mrcnn::as_stream(stream), w, u, d->K, d->C, (const float *)nullptr);
+    return mrcnn::check_launch("conv3x3_wino_filter");
+}
+
 extern "C" int mrcnn_conv3x3_wino_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
-                                      const float *scale, const float *shift, float *y,
-                                      int epi_flags, float *v, void *ws, void *stream)
+                                      const float *u_pre, const float *scale, const float *shift,
+                                      float *y, int epi_flags, float *v, void *ws, void *stream)
 {
     if (int rc = wino_check(d, "conv3x3_wino_fwd")) return rc;
-    MRCNN_REQUIRE(x && w && y && ws, "conv3x3_wino_fwd: null pointer");
+    MRCNN_REQUIRE(x && (w || u_pre) && y && ws, "conv3x3_wino_fwd: null pointer");
     MRCNN_REQUIRE((epi_flags & ~(MRCNN_EPI_AFFINE | MRCNN_EPI_BIAS | MRCNN_EPI_RELU)) == 0,
                   "conv3x3_wino_fwd: only AFFINE or BIAS, and RELU epilogues");
     MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_AFFINE) || scale, "conv3x3_wino_fwd: affine flag without scale");
@@ -405,12 +424,16 @@ extern "C" int mrcnn_conv3x3_wino_fwd(const mrcnn_conv_desc *d, const float *x, 
                   "conv3x3_wino_fwd: the bias flag takes the bias in `shift` and excludes AFFINE");
     hipStream_t s = mrcnn::as_stream(stream);
     const WinoGeom g = wino_geom(d);
-    float *u = (float *)ws;
-    float *m = u + wino_u_floats(d);
+    float *u_ws = (float *)ws;
+    float *m = u_ws + wino_u_floats(d);
     float *vbuf = v ? v : m + wino_plane_floats(d, d->K);
-    hipLaunchKernelGGL((wino_filter_transform_kernel<false>),
-                       dim3((d->C + 31) / 32, (d->K + 31) / 32), dim3(256), 0, s, w, u, d->K, d->C,
-                       (const float *)nullptr);
+    const float *u = u_pre;
+    if (!u) {
+        hipLaunchKernelGGL((wino_filter_transform_kernel<false>),
+                           dim3((d->C + 31) / 32, (d->K + 31) / 32), dim3(256), 0, s, w, u_ws, d->K,
+                           d->C, (const float *)nullptr);
+        u = u_ws;
+    }
     wino_launch_data_transform<false>(x, vbuf, g, d->C, s);
     if (int rc = wino_batched_gemm(vbuf, u, m, g.T, d->K, d->C, s)) return rc;
     WinoOutParams o = {};

@@ -90,7 +90,8 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.wino = uses_winograd(d) and residual is None and (b is None or scale is None)
         if ctx.wino and (WINOGRAD_TRAIN_FORWARD in (True, 'conv2d')
                          or not (_CONV_RECORDS_GRAPH and any(ctx.needs_input_grad))):
-            y, _ = wino_fwd(x, Wc, d, scale, shift if scale is not None else b, relu)
+            y, _ = wino_fwd(x, Wc, d, scale, shift if scale is not None else b, relu,
+                            cache_for=None if _CONV_RECORDS_GRAPH else W)
         else:
             y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
             _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(b),
@@ -409,9 +410,34 @@ def _wino_ws(d, device, tag='wino'):
     return _lib.workspace(_lib.load().mrcnn_conv3x3_wino_workspace_bytes(ctx_desc(d)), device, tag)
 
 
-def wino_fwd(x, Wc, d, scale, shift, relu, keep_v=False):
+# Transformed filters of inference calls, keyed by the filter tensor: valid while the tensor has
+# not been written (torch bumps ``_version`` on every in-place update, the optimizer's included).
+_wino_u_cache = {}
+
+
+def weights_changed():
+    """Parameters were written outside torch's version tracking (the SGD kernel updates the flat
+    arena through a raw pointer): drop every cached transformed filter."""
+    _wino_u_cache.clear()
+
+
+def _cached_filter_transform(W, Wc, d):
+    key = id(W)
+    hit = _wino_u_cache.get(key)
+    if hit is not None and hit[0] is W and hit[1] == W._version and hit[2].device == Wc.device:
+        return hit[2]
+    u = torch.empty((_lib.load().mrcnn_conv3x3_wino_u_bytes(ctx_desc(d)) // 4,),
+                    dtype=torch.float32, device=Wc.device)
+    _lib.call('mrcnn_conv3x3_wino_filter', ctx_desc(d), _lib.ptr(Wc), _lib.ptr(u), _lib.stream_ptr())
+    _wino_u_cache[key] = (W, W._version, u)
+    return u
+
+
+def wino_fwd(x, Wc, d, scale, shift, relu, keep_v=False, cache_for=None):
     """y = relu?(affine?(conv3x3(x))) — ``scale`` None with a ``shift``: plain bias — and, with
-    ``keep_v``, the transformed input (36, tiles, C) for the weight gradient."""
+    ``keep_v``, the transformed input (36, tiles, C) for the weight gradient.  ``cache_for``: the
+    parameter tensor ``Wc`` was taken from; its transformed filter is then built once and reused
+    until the parameter is written (inference)."""
     flags = (EPI_AFFINE if scale is not None else (EPI_BIAS if shift is not None else 0)) \
         | (EPI_RELU if relu else 0)
     y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
@@ -419,9 +445,10 @@ def wino_fwd(x, Wc, d, scale, shift, relu, keep_v=False):
     if keep_v:
         v = torch.empty((_lib.load().mrcnn_conv3x3_wino_v_bytes(ctx_desc(d)) // 4,),
                         dtype=torch.float32, device=x.device)
-    _lib.call('mrcnn_conv3x3_wino_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(scale),
-              _lib.ptr(shift), _lib.ptr(y), flags, _lib.ptr(v), _lib.ptr(_wino_ws(d, x.device)),
-              _lib.stream_ptr())
+    u = _cached_filter_transform(cache_for, Wc, d) if cache_for is not None else None
+    _lib.call('mrcnn_conv3x3_wino_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(u),
+              _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y), flags, _lib.ptr(v),
+              _lib.ptr(_wino_ws(d, x.device)), _lib.stream_ptr())
     return y, v
 
 
@@ -665,7 +692,8 @@ class _StageFn(torch.autograd.Function):
                                      or len(blocks) in WINOGRAD_TRAIN_FORWARD_BLOCKS):
                 # (with a weight gradient to come, the transformed input is kept for it)
                 h2, v2 = wino_fwd(h1, nhwc(W2), d2, s2, b2, True,
-                                  keep_v=bool(ctx.needs_input_grad[4 + pos + 3]))
+                                  keep_v=training and bool(ctx.needs_input_grad[4 + pos + 3]),
+                                  cache_for=None if training else W2)
             else:
                 h2 = _fwd_raw(h1, nhwc(W2), d2, s2, b2, None, True)
             d4 = None

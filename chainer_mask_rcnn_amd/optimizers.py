@@ -191,6 +191,7 @@ class MomentumSGD(object):
                 _lib.call('mrcnn_sgd_momentum_wd_ex', _lib.ptr(a.values[lo:hi]),
                           _lib.ptr(a.grads[lo:hi]), _lib.ptr(a.momenta[lo:hi]), hi - lo,
                           float(lr), float(momentum), float(wd), float(scale), 1, _lib.stream_ptr())
+            conv.weights_changed()
             for job in jobs:                       # keep the operands alive until S2 is done
                 for t in job[1:]:
                     if isinstance(t, torch.Tensor):
@@ -287,6 +288,8 @@ class MomentumSGD(object):
                       _lib.ptr(a.grads[lo:hi]), _lib.ptr(a.momenta[lo:hi]), hi - lo,
                       float(self.lr), float(self.momentum), float(self.weight_decay),
                       float(grad_scale), 1 if zero_grads else 0, _lib.stream_ptr())
+        from .functions import conv
+        conv.weights_changed()       # the kernel writes the arena behind torch's version counters
         if zero_grads and not all_written:
             a.grads.zero_()              # slices of skipped parameters (normally there are none)
         a.epoch += 1

@@ -220,9 +220,11 @@ int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float 
  * fp32 error max 3.4e-6 / rms 3.7e-7 of the tensor scale against an fp64 direct convolution
  * (direct fp32: 3.5e-7 / 5.7e-8), inside the 1e-4 parity tolerance.
  *   fwd:   y = epi(conv(x, w)), epi_flags: MRCNN_EPI_AFFINE (scale, shift) or MRCNN_EPI_BIAS
- *          (the bias in `shift`, scale NULL), and MRCNN_EPI_RELU.  v: NULL or a
- *          buffer of mrcnn_conv3x3_wino_v_bytes(d) that receives the transformed input
- *          (36 x tiles x C), which mrcnn_conv3x3_wino_wgrad consumes.
+ *          (the bias in `shift`, scale NULL), and MRCNN_EPI_RELU.  u: NULL (the filter is
+ *          transformed per call) or the output of mrcnn_conv3x3_wino_filter for this w
+ *          (mrcnn_conv3x3_wino_u_bytes(d) bytes; inference keeps it while w is unchanged, w may
+ *          then be NULL).  v: NULL or a buffer of mrcnn_conv3x3_wino_v_bytes(d) that receives the
+ *          transformed input (36 x tiles x C), which mrcnn_conv3x3_wino_wgrad consumes.
  *   dgrad: gx = (dgrad(gy * w_row_scale[k]) * out_scale[c]) masked by (out_mask_y > 0)
  *          (any of the three may be NULL; same meaning as in mrcnn_conv2d_dgrad_wt).
  *   wgrad: gw (K,3,3,C) from gy and exactly one of x (the raw input, transformed into the
@@ -231,9 +233,11 @@ int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float 
  * ws: scratch of mrcnn_conv3x3_wino_workspace_bytes(d), private to the stream. */
 int64_t mrcnn_conv3x3_wino_v_bytes(const mrcnn_conv_desc *d);
 int64_t mrcnn_conv3x3_wino_workspace_bytes(const mrcnn_conv_desc *d);
+int64_t mrcnn_conv3x3_wino_u_bytes(const mrcnn_conv_desc *d);
+int mrcnn_conv3x3_wino_filter(const mrcnn_conv_desc *d, const float *w, float *u, void *stream);
 int mrcnn_conv3x3_wino_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
-                           const float *scale, const float *shift, float *y, int epi_flags,
-                           float *v, void *ws, void *stream);
+                           const float *u, const float *scale, const float *shift, float *y,
+                           int epi_flags, float *v, void *ws, void *stream);
 int mrcnn_conv3x3_wino_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w,
                              const float *w_row_scale, float *gx, const float *out_scale,
                              const float *out_mask_y, void *ws, void *stream);

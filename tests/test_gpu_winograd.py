@@ -187,3 +187,47 @@ def test_conv2d_winograd_route_bias_relu(dev, train_forward):
     finally:
         C.wino_fwd, C.wino_dgrad, C.wino_wgrad_into = orig
         C.WINOGRAD_MIN_WORK, C.WINOGRAD_TRAIN_FORWARD = saved
+
+
+def test_inference_filter_cache_follows_weight_updates(dev):
+    """Inference calls reuse the transformed filter of an unchanged parameter; an optimizer step
+    (which writes the flat arena behind torch's version counters) and an in-place torch write both
+    drop it."""
+    from chainer_mask_rcnn_amd import functions as F, optimizers
+    torch.manual_seed(1)
+    saved = C.WINOGRAD_MIN_WORK
+    C.WINOGRAD_MIN_WORK = 0
+    try:
+        conv = torch.nn.Module()
+        conv.W = torch.nn.Parameter(torch.randn(256, 256, 3, 3, device=dev) * 0.02)
+        x = torch.randn(2, 256, 12, 16, device=dev)
+
+        def infer():
+            with torch.no_grad():
+                return F.conv2d(x, conv.W, None, stride=1, pad=1)
+
+        def direct():
+            C.USE_WINOGRAD = False
+            try:
+                return infer()
+            finally:
+                C.USE_WINOGRAD = True
+        y0 = infer()
+        assert id(conv.W) in C._wino_u_cache
+        u0 = C._wino_u_cache[id(conv.W)][2]
+        assert infer() is not None and C._wino_u_cache[id(conv.W)][2] is u0     # reused
+        _close(y0.cpu().numpy(), direct().cpu().numpy())
+        # one SGD step through the arena
+        opt = optimizers.MomentumSGD(lr=0.5, momentum=0.)
+        opt.setup(conv)
+        opt.update(lambda: F.conv2d(x, conv.W, None, stride=1, pad=1).sum() * 1e-3)
+        assert id(conv.W) not in C._wino_u_cache
+        y1 = infer()
+        assert not torch.equal(y1, y0)
+        _close(y1.cpu().numpy(), direct().cpu().numpy())
+        # an in-place torch write
+        with torch.no_grad():
+            conv.W.mul_(0.5)
+        _close(infer().cpu().numpy(), direct().cpu().numpy())
+    finally:
+        C.WINOGRAD_MIN_WORK = saved
