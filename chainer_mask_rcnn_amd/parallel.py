@@ -296,6 +296,8 @@ class DataParallelGradSync(object):
                     flat = t.data.clone(memory_format=torch.contiguous_format)
                     self.exchange.broadcast(flat, src=0)
                     t.data.copy_(flat)
+        from .functions import conv
+        conv.weights_changed()      # the broadcast wrote parameters behind torch's version counters
         # units: a bottleneck block, or a leaf layer, by MODULE IDENTITY (no name matching)
         owner = {}
         from .models.resnet_extractor import Bottleneck
