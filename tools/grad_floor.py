@@ -17,6 +17,12 @@ from test_gpu_model import _build, _BLOCKS, _rel, H, W   # noqa: E402
 def run(n_layers):
     dev = torch.device('cuda:0')
     model, chain, imgs, bboxes, labels, masks = _build(dev, n_layers)
+    damp = float(os.environ.get('HEAD_DAMP', '1'))
+    if damp != 1:
+        with torch.no_grad():
+            for name, m in model.head.res5.named_modules():
+                if name.endswith('bn3'):
+                    m.W.mul_(damp)
     np.random.seed(123)
     loss = chain(torch.tensor(imgs, device=dev), bboxes, labels, masks, [1., 1.])
     loss.backward()
@@ -40,14 +46,25 @@ def run(n_layers):
         feat = ref_model.extractor(torch.tensor(imgs), P, blocks=_BLOCKS[n_layers])
         rl, rs = ref_model.rpn(feat, P, 15)
         cls_locs, sc, mk = ref_model.head(feat, cat(s_rois, torch.float32), cat(s_idx, torch.int32), P, 81, 14)
+        if dtype == torch.float64:
+            print('  logits: max |score| %.3g rms %.3g; mask logits max %.3g; cls_locs max %.3g' % (
+                sc.abs().max().item(), sc.pow(2).mean().sqrt().item(), mk.abs().max().item(), cls_locs.abs().max().item()))
         parts = ref_model.losses(rl, rs, cat(r_locs, torch.float32), cat(r_labels, torch.int32),
                                  cls_locs, sc, mk, cat(g_locs, torch.float32),
                                  cat(g_labels, torch.int32), cat(g_masks, torch.int32))
         sum(parts).backward()
         grads[dtype] = {n: P[n].grad for n, _ in model.named_parameters() if P[n].grad is not None}
-    def stats(got, ref):
+    bad_rows = {}
+
+    def stats(got, ref, name=None):
         got, ref = got.detach().cpu().double(), ref.detach().double()
-        err = ((got - ref).abs() / ref.abs().max().clamp_min(1e-12)).flatten()
+        e2 = (got - ref).abs() / ref.abs().max().clamp_min(1e-12)
+        if name is not None:
+            rows = e2.reshape(e2.shape[0], -1)
+            nbad = int((rows.max(1).values > 1e-4).sum())
+            if nbad:
+                bad_rows[name] = (nbad, rows.shape[0])
+        err = e2.flatten()
         k = max(1, int(err.numel() * 0.999))
         return float(err.max()), float(err.kthvalue(k).values), float((err > 1e-4).double().mean()), \
             float(err.pow(2).mean().sqrt())
@@ -57,19 +74,20 @@ def run(n_layers):
                 or name.startswith('extractor.res2') or '.bn' in name:
             continue
         g64 = grads[torch.float64][name]
-        rows.append((name,) + stats(p.grad, g64) + stats(grads[torch.float32][name], g64))
+        rows.append((name,) + stats(p.grad, g64, name) + stats(grads[torch.float32][name], g64))
     rows.sort(key=lambda r: -r[3])
     print('R-%d: worst HIP max %.2e frac %.2e, worst CPU-fp32 max %.2e frac %.2e' % (
         n_layers, max(r[1] for r in rows), max(r[3] for r in rows), max(r[5] for r in rows),
         max(r[7] for r in rows)))
-    for r in rows[:4]:
+    print('  tensors with rows beyond 1e-4 (rows beyond / rows):', bad_rows)
+    for r in rows[:3]:
         print('  %-34s hip max %.1e p99.9 %.1e frac %.1e rms %.1e | cpu32 max %.1e p99.9 %.1e frac %.1e rms %.1e' % r)
 
 
 if __name__ == '__main__':
     from chainer_mask_rcnn_amd.functions import conv as C
-    for use, fw, blk in ((True, 'conv2d', ()), (True, 'conv2d', (2,)), (True, 'conv2d', (1,)), (True, 'conv2d', (0,))):
+    for use, fw, blk in ((True, 'conv2d', ()), (True, True, ())):
         C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD, C.WINOGRAD_TRAIN_FORWARD_BLOCKS = use, fw, blk
         print('Winograd backward:', use, ' Winograd train forward:', fw, blk)
-        for n in (101,):
+        for n in (50, 101):
             run(n)
