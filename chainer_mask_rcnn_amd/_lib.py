@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MRCNN_HIP_LIB') or os.path.join(_HERE, 'libmrcnn_hip.so')   # override: developer A/B builds
 
-EPI_BIAS, EPI_AFFINE, EPI_RESIDUAL, EPI_RELU, EPI_ACCUM = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_AFFINE, EPI_RESIDUAL, EPI_RELU, EPI_ACCUM, EPI_EXACT_SIGNS = 1, 2, 4, 8, 16, 32
 
 c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     'mrcnn_conv3x3_wino_u_bytes': (c_i64, [_DP]),
     'mrcnn_conv3x3_wino_filter': (c_int, [_DP] + [c_vp] * 3),
     'mrcnn_conv3x3_wino_fwd': (c_int, [_DP] + [c_vp] * 6 + [c_int] + [c_vp] * 3),
+    'mrcnn_conv3x3_wino_fixup_count': (c_int, [_DP, c_vp, c_vp, c_vp]),
     'mrcnn_conv3x3_wino_dgrad': (c_int, [_DP] + [c_vp] * 8),
     'mrcnn_conv3x3_wino_wgrad': (c_int, [_DP] + [c_vp] * 7),
     'mrcnn_filter_flip_transpose': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),

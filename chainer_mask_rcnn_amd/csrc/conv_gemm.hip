@@ -1197,6 +1197,7 @@ void launch_remainder(const GemmParams &p, int rows_lo, hipStream_t s)
     launch_split_rows<MODE>(p, rows_lo, (int)splits, total_slices, s);
 }
 
+extern float g_wino_ambiguity;
 int g_small_whole_max = 1024, g_small_rem_max = 154;   // developer knobs (A/B)
 int g_small_m_split = 0;          // mrcnn_set_tuning("small_m_split", target workgroups per CU)
 
@@ -1359,6 +1360,10 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "fused_tail") == 0) {
         g_fused_tail = value == 1 ? 512 : value;
+        return 0;
+    }
+    if (strcmp(name, "wino_ambiguity_ppb") == 0) {
+        g_wino_ambiguity = 1e-9f * (float)value;
         return 0;
     }
     if (strcmp(name, "small_whole_max") == 0) {

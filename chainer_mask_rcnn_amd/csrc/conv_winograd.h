@@ -56,6 +56,16 @@ __device__ __forceinline__ void wino_at(const T (&m)[6], T (&y)[4])
     y[2] = s12 + 0.25f * m[3] + 4.f * m[4];
     y[3] = d12 + 0.125f * m[3] - 8.f * m[4] + m[5];
 }
+// |A^T| |m|: bound of the rounding-error propagation through y = A^T m
+template <typename T>
+__device__ __forceinline__ void wino_at_abs(const T (&m)[6], T (&y)[4])
+{
+    const T s12 = m[1] + m[2];
+    y[0] = m[0] + s12 + m[3] + m[4];
+    y[1] = s12 + 0.5f * m[3] + 2.f * m[4];
+    y[2] = s12 + 0.25f * m[3] + 4.f * m[4];
+    y[3] = s12 + 0.125f * m[3] + 8.f * m[4] + m[5];
+}
 // t = G' g  (F(3,4) filter-side matrix with its rows scaled to integers; the inverse scales
 // 1, 1/3, 1/3, 1/15, 1/15, 1 sit in A'^T, kWgradAT)
 template <typename T>
@@ -156,7 +166,19 @@ struct WinoOutParams {
     const float *scale, *shift, *mask;
     int H, W, K, TH, TW, flags;
     int64_t T;
+    // FIXUP: outputs whose pre-activation lies within the propagated rounding bound of zero are
+    // appended to a list ((pixel, channel) pairs) and recomputed directly by wino_fixup_kernel
+    int *fix_count;
+    int2 *fix_list;
+    int fix_cap;
+    float ambiguity;
 };
+// Relative rounding per stage (input transform, fp32 GEMM over C channels, output transform)
+// propagated as |A^T| |M| |A|; the factor is ~8x the largest ratio |y - y_fp64| / (|A^T||M||A|)
+// measured over the head / RPN shapes (tests/test_gpu_winograd.py pins it).
+float g_wino_ambiguity = 4e-6f;      // mrcnn_set_tuning("wino_ambiguity_ppb", parts per 1e9)
+
+template <bool FIXUP>
 __global__ void __launch_bounds__(256) wino_output_transform_kernel(const WinoOutParams p)
 {
     const int k2n = p.K >> 1;
@@ -191,6 +213,7 @@ __global__ void __launch_bounds__(256) wino_output_transform_kernel(const WinoOu
             }
     }
     F2 s[4][6];
+    F2 sa[FIXUP ? 4 : 1][6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
         F2 col[6], o[4];
@@ -199,6 +222,13 @@ __global__ void __launch_bounds__(256) wino_output_transform_kernel(const WinoOu
         wino_at(col, o);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i][b] = o[i];
+        if constexpr (FIXUP) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) col[a] = F2{fabsf(col[a].x), fabsf(col[a].y)};
+            wino_at_abs(col, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sa[i][b] = o[i];
+        }
     }
     F2 sc = {1.f, 1.f}, sh = {0.f, 0.f};
     const bool aff = (p.flags & (MRCNN_EPI_AFFINE | MRCNN_EPI_BIAS)) != 0;
@@ -209,19 +239,81 @@ __global__ void __launch_bounds__(256) wino_output_transform_kernel(const WinoOu
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        F2 o[4];
+        F2 o[4], ob[4];
         wino_at(s[i], o);
+        if constexpr (FIXUP) wino_at_abs(sa[i], ob);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (y0 + i >= p.H || x0 + j >= p.W) continue;
             F2 v = o[j];
             if (aff) { v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; }
+            if constexpr (FIXUP) {
+                const float bx = p.ambiguity * ob[j].x * fabsf(sc.x);
+                const float by = p.ambiguity * ob[j].y * fabsf(sc.y);
+                const int pix = (int)(n * p.H * p.W) + (y0 + i) * p.W + x0 + j;
+                if (fabsf(v.x) < bx) {
+                    const int at = atomicAdd(p.fix_count, 1);
+                    if (at < p.fix_cap) p.fix_list[at] = make_int2(pix, k);
+                }
+                if (fabsf(v.y) < by) {
+                    const int at = atomicAdd(p.fix_count, 1);
+                    if (at < p.fix_cap) p.fix_list[at] = make_int2(pix, k + 1);
+                }
+            }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
             if (p.mask) {
                 v.x = mk[i][j].x > 0.f ? v.x : 0.f;
                 v.y = mk[i][j].y > 0.f ? v.y : 0.f;
             }
             *reinterpret_cast<F2 *>(p.y + obase + ((int64_t)(y0 + i) * p.W + x0 + j) * p.K) = v;
+        }
+    }
+}
+
+// ---- direct recomputation of the listed outputs: one wave per (pixel, channel) ------------------
+// y = relu?(dot(x patch, w[k]) * scale[k] + shift[k]); lanes stride over channels (16 B each),
+// pairwise wave reduction: the rounding of a direct fp32 dot product.
+struct WinoFixParams {
+    const float *x, *w, *scale, *shift;
+    float *y;
+    const int *count;
+    const int2 *list;
+    int cap, H, W, C, K, flags;
+};
+__global__ void __launch_bounds__(256) wino_fixup_kernel(const WinoFixParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)(gridDim.x * 4);
+    const int n_items = min(*p.count, p.cap);
+    for (int it = wave; it < n_items; it += nwaves) {
+        const int2 e = p.list[it];
+        const int pix = e.x, k = e.y;
+        const int n = pix / (p.H * p.W), rem = pix - n * (p.H * p.W);
+        const int yy = rem / p.W, xx = rem - yy * p.W;
+        float acc = 0.f;
+        for (int r = 0; r < 3; ++r) {
+            const int iy = yy + r - 1;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int ix = xx + s - 1;
+                if ((unsigned)ix >= (unsigned)p.W) continue;
+                const float *xp = p.x + ((int64_t)(n * p.H + iy) * p.W + ix) * p.C;
+                const float *wp = p.w + ((int64_t)k * 9 + r * 3 + s) * p.C;
+                for (int c = lane * 4; c < p.C; c += 256) {
+                    const float4 a = *reinterpret_cast<const float4 *>(xp + c);
+                    const float4 b = *reinterpret_cast<const float4 *>(wp + c);
+                    acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) {
+            float v = acc;
+            if (p.flags & (MRCNN_EPI_AFFINE | MRCNN_EPI_BIAS))
+                v = v * (p.scale ? p.scale[k] : 1.f) + (p.shift ? p.shift[k] : 0.f);
+            if (p.flags & MRCNN_EPI_RELU) v = fmaxf(v, 0.f);
+            p.y[(int64_t)pix * p.K + k] = v;
         }
     }
 }
@@ -417,8 +509,11 @@ extern "C" int mrcnn_conv3x3_wino_fwd(const mrcnn_conv_desc *d, const float *x, 
 {
     if (int rc = wino_check(d, "conv3x3_wino_fwd")) return rc;
     MRCNN_REQUIRE(x && (w || u_pre) && y && ws, "conv3x3_wino_fwd: null pointer");
-    MRCNN_REQUIRE((epi_flags & ~(MRCNN_EPI_AFFINE | MRCNN_EPI_BIAS | MRCNN_EPI_RELU)) == 0,
-                  "conv3x3_wino_fwd: only AFFINE or BIAS, and RELU epilogues");
+    MRCNN_REQUIRE((epi_flags & ~(MRCNN_EPI_AFFINE | MRCNN_EPI_BIAS | MRCNN_EPI_RELU |
+                                 MRCNN_EPI_EXACT_SIGNS)) == 0,
+                  "conv3x3_wino_fwd: only AFFINE or BIAS, RELU and EXACT_SIGNS");
+    MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_EXACT_SIGNS) || w,
+                  "conv3x3_wino_fwd: EXACT_SIGNS needs the filter itself");
     MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_AFFINE) || scale, "conv3x3_wino_fwd: affine flag without scale");
     MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_BIAS) || (shift && !scale && !(epi_flags & MRCNN_EPI_AFFINE)),
                   "conv3x3_wino_fwd: the bias flag takes the bias in `shift` and excludes AFFINE");
@@ -438,12 +533,31 @@ extern "C" int mrcnn_conv3x3_wino_fwd(const mrcnn_conv_desc *d, const float *x, 
     if (int rc = wino_batched_gemm(vbuf, u, m, g.T, d->K, d->C, s)) return rc;
     WinoOutParams o = {};
     o.m = m; o.y = y; o.scale = scale; o.shift = shift;
-    o.H = d->H; o.W = d->W; o.K = d->K; o.TH = g.TH; o.TW = g.TW; o.flags = epi_flags; o.T = g.T;
+    o.H = d->H; o.W = d->W; o.K = d->K; o.TH = g.TH; o.TW = g.TW;
+    o.flags = epi_flags & ~MRCNN_EPI_EXACT_SIGNS; o.T = g.T;
+    const bool fixup = (epi_flags & MRCNN_EPI_EXACT_SIGNS) != 0;
+    if (fixup) {
+        // behind everything the forward uses: [count (16 B) | list]
+        float *fix = (float *)ws + wino_u_floats(d) + 2 * wino_plane_floats(d, std::max(d->C, d->K));
+        o.fix_count = (int *)fix;
+        o.fix_list = (int2 *)(fix + 4);
+        o.fix_cap = (int)std::min<int64_t>(1 << 20, (8 * wino_u_floats(d) - 4) / 2);
+        o.ambiguity = g_wino_ambiguity;
+        MRCNN_HIP_TRY(hipMemsetAsync(o.fix_count, 0, 16, s));
+    }
     {
         mrcnn::ProfScope prof(mrcnn::PROF_WINO_TRANSFORM, 0.,
                               4.0 * d->K * (36.0 * g.T + (double)d->N * d->H * d->W), s);
-        hipLaunchKernelGGL(wino_output_transform_kernel,
-                           dim3((unsigned)mrcnn::ceil_div(g.T * (d->K / 2), 256)), dim3(256), 0, s, o);
+        const dim3 grid((unsigned)mrcnn::ceil_div(g.T * (d->K / 2), 256));
+        if (fixup) hipLaunchKernelGGL(wino_output_transform_kernel<true>, grid, dim3(256), 0, s, o);
+        else hipLaunchKernelGGL(wino_output_transform_kernel<false>, grid, dim3(256), 0, s, o);
+    }
+    if (fixup) {
+        WinoFixParams f = {};
+        f.x = x; f.w = w; f.scale = scale; f.shift = shift; f.y = y;
+        f.count = o.fix_count; f.list = o.fix_list; f.cap = o.fix_cap;
+        f.H = d->H; f.W = d->W; f.C = d->C; f.K = d->K; f.flags = o.flags;
+        hipLaunchKernelGGL(wino_fixup_kernel, dim3(1024), dim3(256), 0, s, f);
     }
     return mrcnn::check_launch("conv3x3_wino_fwd");
 }
@@ -475,7 +589,7 @@ extern "C" int mrcnn_conv3x3_wino_dgrad(const mrcnn_conv_desc *d, const float *g
     {
         mrcnn::ProfScope prof(mrcnn::PROF_WINO_TRANSFORM, 0.,
                               4.0 * d->C * (36.0 * g.T + (out_mask_y ? 2.0 : 1.0) * d->N * d->H * d->W), s);
-        hipLaunchKernelGGL(wino_output_transform_kernel,
+        hipLaunchKernelGGL(wino_output_transform_kernel<false>,
                            dim3((unsigned)mrcnn::ceil_div(g.T * (d->C / 2), 256)), dim3(256), 0, s, o);
     }
     return mrcnn::check_launch("conv3x3_wino_dgrad");
@@ -529,4 +643,17 @@ extern "C" int mrcnn_conv3x3_wino_wgrad(const mrcnn_conv_desc *d, const float *x
                        0, s, (const float *)slabs, splits, p.split_stride, gw, out_row_scale, d->K,
                        d->C);
     return mrcnn::check_launch("conv3x3_wino_wgrad");
+}
+
+// number of outputs the last EXACT_SIGNS forward on this workspace recomputed (test / diagnostics;
+// synchronises the stream)
+extern "C" int mrcnn_conv3x3_wino_fixup_count(const mrcnn_conv_desc *d, const void *ws, void *stream,
+                                              int *count)
+{
+    MRCNN_REQUIRE(d && ws && count, "conv3x3_wino_fixup_count: null pointer");
+    const float *fix = (const float *)ws + wino_u_floats(d) +
+                       2 * wino_plane_floats(d, std::max(d->C, d->K));
+    MRCNN_HIP_TRY(hipMemcpyAsync(count, fix, sizeof(int), hipMemcpyDeviceToHost, mrcnn::as_stream(stream)));
+    MRCNN_HIP_TRY(hipStreamSynchronize(mrcnn::as_stream(stream)));
+    return 0;
 }

@@ -12,7 +12,7 @@ NHWC / KRSC layout the HIP kernels consume.
 import torch
 
 from .. import _lib
-from .._lib import ConvDesc, EPI_BIAS, EPI_AFFINE, EPI_RESIDUAL, EPI_RELU, EPI_ACCUM
+from .._lib import ConvDesc, EPI_BIAS, EPI_AFFINE, EPI_RESIDUAL, EPI_RELU, EPI_ACCUM, EPI_EXACT_SIGNS
 from ._layout import nhwc, empty_nhwc
 
 
@@ -91,7 +91,8 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.wino and (WINOGRAD_TRAIN_FORWARD in (True, 'conv2d')
                          or not (_CONV_RECORDS_GRAPH and any(ctx.needs_input_grad))):
             y, _ = wino_fwd(x, Wc, d, scale, shift if scale is not None else b, relu,
-                            cache_for=None if _CONV_RECORDS_GRAPH else W)
+                            cache_for=None if _CONV_RECORDS_GRAPH else W,
+                            exact_signs=relu and _CONV_RECORDS_GRAPH and WINOGRAD_EXACT_SIGNS)
         else:
             y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
             _lib.call('mrcnn_conv2d_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(b),
@@ -389,15 +390,23 @@ WINOGRAD_MIN_WORK = int(_os.environ.get('MRCNN_WINO_MIN_WORK', 1 << 27))        
 #   * the fused stages (res5 in the RoI head) do NOT.  The forward difference itself is benign
 #     (Winograd vs direct output: rms 9e-7, max 3e-6 of the output scale at every head layer of
 #     both test nets, activations max/rms 7-11: tools/exp/head_activation_stats.py), but it is
-#     ten times the direct kernel's rounding, so ten times as many ReLU decisions of units
-#     sitting at zero flip.  On the R-101 instance one such flip in res5.b1 carries enough
-#     gradient that 69 of the 512 rows of head.res5.b1.conv{1,2}.W (and a few rows of most
-#     backbone layers) moved beyond 1e-4 of the tensor scale — 0.2 % of the entries where the
-#     parity test allows 0.1 %.  (R-50, and the same R-101 with res5's residual branches damped
-#     like res4's, pass with the forward routed: it is a lottery, lost once.)
+#     ten times the direct kernel's rounding, and every ReLU DOWNSTREAM of the layer (conv3 +
+#     shortcut, the next blocks) sees it: ten times as many decisions of units sitting at zero
+#     flip.  On the R-101 instance one such flip behind res5.b1.conv2 carries enough gradient
+#     that 69 of the 512 rows of head.res5.b1.conv{1,2}.W (and a few rows of most backbone
+#     layers) moved beyond 1e-4 of the tensor scale — 0.2 % of the entries where the parity
+#     test allows 0.1 %.  (R-50, and the same R-101 with res5's residual branches damped like
+#     res4's, pass with the forward routed: it is a lottery, lost once.)
+# A routed forward inside a recorded graph asks for MRCNN_EPI_EXACT_SIGNS: outputs within the
+# propagated rounding bound of zero (5 in 10^5) are recomputed as direct dot products, so the
+# layer's OWN ReLU decisions agree with float64 at least as often as the direct kernel's
+# (0-1 disagreements per 25 M outputs, direct kernel 4-6, plain Winograd 12-22:
+# tools/exp/wino_signs.py).  That settles the RPN's conv1, behind whose ReLU there is only a 1x1
+# convolution and the losses; it cannot help the ReLUs further down a fused stage.
 # Without a graph (inference) every routed layer's forward takes it: only the per-op tolerance
 # applies there and it holds with a 30x margin.
 WINOGRAD_TRAIN_FORWARD = 'conv2d'     # False / 'conv2d' / 'stage' / True (both)
+WINOGRAD_EXACT_SIGNS = True          # recorded graphs: ReLU decisions recomputed directly near zero
 WINOGRAD_TRAIN_FORWARD_BLOCKS = ()    # developer: block indices of a fused stage whose conv2 forward is routed
 WINOGRAD_DGRAD = True        # developer switches (error attribution, A/B timing)
 WINOGRAD_WGRAD = True
@@ -437,13 +446,14 @@ def _cached_filter_transform(W, Wc, d):
     return u
 
 
-def wino_fwd(x, Wc, d, scale, shift, relu, keep_v=False, cache_for=None):
+def wino_fwd(x, Wc, d, scale, shift, relu, keep_v=False, cache_for=None, exact_signs=False):
     """y = relu?(affine?(conv3x3(x))) — ``scale`` None with a ``shift``: plain bias — and, with
     ``keep_v``, the transformed input (36, tiles, C) for the weight gradient.  ``cache_for``: the
     parameter tensor ``Wc`` was taken from; its transformed filter is then built once and reused
-    until the parameter is written (inference)."""
+    until the parameter is written (inference).  ``exact_signs``: outputs within the Winograd
+    rounding bound of zero are recomputed directly (MRCNN_EPI_EXACT_SIGNS)."""
     flags = (EPI_AFFINE if scale is not None else (EPI_BIAS if shift is not None else 0)) \
-        | (EPI_RELU if relu else 0)
+        | (EPI_RELU if relu else 0) | (EPI_EXACT_SIGNS if exact_signs else 0)
     y = empty_nhwc((d.N, d.K, d.P, d.Q), x.device)
     v = None
     if keep_v:
@@ -697,7 +707,8 @@ class _StageFn(torch.autograd.Function):
                 # (with a weight gradient to come, the transformed input is kept for it)
                 h2, v2 = wino_fwd(h1, nhwc(W2), d2, s2, b2, True,
                                   keep_v=training and bool(ctx.needs_input_grad[4 + pos + 3]),
-                                  cache_for=None if training else W2)
+                                  cache_for=None if training else W2,
+                                  exact_signs=training and WINOGRAD_EXACT_SIGNS)
             else:
                 h2 = _fwd_raw(h1, nhwc(W2), d2, s2, b2, None, True)
             d4 = None

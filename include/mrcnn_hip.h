@@ -144,6 +144,7 @@ int mrcnn_nms_sorted_batched(const float *bbox, const int32_t *n_dev, int groups
 #define MRCNN_EPI_RESIDUAL 4   /* y += residual[m,c]                            */
 #define MRCNN_EPI_RELU     8   /* y = max(y,0)                                  */
 #define MRCNN_EPI_ACCUM    16  /* y += previous contents of y (dgrad fan-in)    */
+#define MRCNN_EPI_EXACT_SIGNS 32 /* mrcnn_conv3x3_wino_fwd only, see there        */
 
 typedef struct {
     int N, H, W, C;        /* input  (N,H,W,C)  NHWC                         */
@@ -220,7 +221,11 @@ int mrcnn_conv2d_wgrad_ex(const mrcnn_conv_desc *d, const float *x, const float 
  * fp32 error max 3.4e-6 / rms 3.7e-7 of the tensor scale against an fp64 direct convolution
  * (direct fp32: 3.5e-7 / 5.7e-8), inside the 1e-4 parity tolerance.
  *   fwd:   y = epi(conv(x, w)), epi_flags: MRCNN_EPI_AFFINE (scale, shift) or MRCNN_EPI_BIAS
- *          (the bias in `shift`, scale NULL), and MRCNN_EPI_RELU.  u: NULL (the filter is
+ *          (the bias in `shift`, scale NULL), and MRCNN_EPI_RELU.  With MRCNN_EPI_EXACT_SIGNS
+ *          every output whose pre-activation lies within the propagated Winograd rounding
+ *          bound of zero (a few in 10^5) is recomputed as a direct fp32 dot product, so the
+ *          ReLU decisions — what a recorded graph's backward masks depend on — have the
+ *          accuracy of the direct kernel (w must be given).  u: NULL (the filter is
  *          transformed per call) or the output of mrcnn_conv3x3_wino_filter for this w
  *          (mrcnn_conv3x3_wino_u_bytes(d) bytes; inference keeps it while w is unchanged, w may
  *          then be NULL).  v: NULL or a buffer of mrcnn_conv3x3_wino_v_bytes(d) that receives the
@@ -238,6 +243,9 @@ int mrcnn_conv3x3_wino_filter(const mrcnn_conv_desc *d, const float *w, float *u
 int mrcnn_conv3x3_wino_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                            const float *u, const float *scale, const float *shift, float *y,
                            int epi_flags, float *v, void *ws, void *stream);
+int mrcnn_conv3x3_wino_fixup_count(const mrcnn_conv_desc *d, const void *ws, void *stream,
+                                   int *count);   /* diagnostics: outputs recomputed by the last
+                                                     EXACT_SIGNS forward on ws (synchronises) */
 int mrcnn_conv3x3_wino_dgrad(const mrcnn_conv_desc *d, const float *gy, const float *w,
                              const float *w_row_scale, float *gx, const float *out_scale,
                              const float *out_mask_y, void *ws, void *stream);

@@ -231,3 +231,44 @@ def test_inference_filter_cache_follows_weight_updates(dev):
         _close(infer().cpu().numpy(), direct().cpu().numpy())
     finally:
         C.WINOGRAD_MIN_WORK = saved
+
+
+def test_exact_signs_fixup(dev):
+    """MRCNN_EPI_EXACT_SIGNS: the ReLU decisions of the Winograd forward, checked against a float64
+    convolution of the same fp32 inputs.  Plain Winograd decides ~3x as many near-zero units
+    differently as the direct kernel; with the fix-up (outputs within the propagated rounding bound
+    of zero recomputed as direct dot products, a few in 10^5) no more than the direct kernel."""
+    import ctypes
+    g = torch.Generator(device='cpu').manual_seed(0)
+    N, Cc, K, H, W = 384, 512, 512, 7, 7
+    x = torch.randn(N, Cc, H, W, generator=g).relu_().mul_(20.)
+    w = torch.randn(K, Cc, 3, 3, generator=g) / (3. * Cc ** 0.5)
+    sc = torch.rand(K, generator=g) * 0.5 + 0.4
+    sh = torch.randn(K, generator=g) * 2.0
+    pre = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1) \
+        * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    pre = pre.to(dev)
+    scale = pre.abs().max().item()
+    xt, wt, sct, sht = nhwc(x.to(dev)), nhwc(w.to(dev)), sc.to(dev), sh.to(dev)
+    d = C.make_desc(xt.shape, wt.shape, 1, 1)
+
+    def wrong(y):
+        bad = (y > 0) != (pre > 0)
+        return int(bad.sum()), (pre.abs()[bad].max().item() / scale if bad.any() else 0.)
+    n_direct, _ = wrong(C._fwd_raw(xt, wt, d, sct, sht, None, True))
+    y_plain, _ = C.wino_fwd(xt, wt, d, sct, sht, True)
+    n_plain, worst_plain = wrong(y_plain)
+    y_fix, _ = C.wino_fwd(xt, wt, d, sct, sht, True, exact_signs=True)
+    n_fix, worst_fix = wrong(y_fix)
+    cnt = ctypes.c_int(0)
+    _lib.call('mrcnn_conv3x3_wino_fixup_count', C.ctx_desc(d), _lib.ptr(C._wino_ws(d, dev)),
+              _lib.stream_ptr(), ctypes.byref(cnt))
+    print('sign disagreements with fp64: direct %d, winograd %d (|pre| up to %.1e of scale), with fix-up %d '
+          '(up to %.1e); %d of %d outputs recomputed' % (n_direct, n_plain, worst_plain, n_fix, worst_fix,
+                                                         cnt.value, pre.numel()))
+    assert n_fix <= max(n_direct, 1) and worst_fix < 2e-7
+    assert 0 < cnt.value < 2e-4 * pre.numel()
+    # everything else is untouched: same values as the plain route except the recomputed outputs
+    changed = int((y_fix != y_plain).sum())
+    assert changed <= cnt.value
+    _close(y_fix.cpu().numpy(), np.maximum(pre.cpu().numpy(), 0))
