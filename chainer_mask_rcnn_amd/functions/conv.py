@@ -407,7 +407,6 @@ WINOGRAD_MIN_WORK = int(_os.environ.get('MRCNN_WINO_MIN_WORK', 1 << 27))        
 # applies there and it holds with a 30x margin.
 WINOGRAD_TRAIN_FORWARD = 'conv2d'     # False / 'conv2d' / 'stage' / True (both)
 WINOGRAD_EXACT_SIGNS = True          # recorded graphs: ReLU decisions recomputed directly near zero
-WINOGRAD_TRAIN_FORWARD_BLOCKS = ()    # developer: block indices of a fused stage whose conv2 forward is routed
 WINOGRAD_DGRAD = True        # developer switches (error attribution, A/B timing)
 WINOGRAD_WGRAD = True
 
@@ -702,8 +701,7 @@ class _StageFn(torch.autograd.Function):
             d2 = make_desc(h1.shape, W2.shape, 1, 1)
             v2 = None
             training = _STAGE_RECORDS_GRAPH and any(ctx.needs_input_grad)
-            if uses_winograd(d2) and (WINOGRAD_TRAIN_FORWARD in (True, 'stage') or not training
-                                     or len(blocks) in WINOGRAD_TRAIN_FORWARD_BLOCKS):
+            if uses_winograd(d2) and (WINOGRAD_TRAIN_FORWARD in (True, 'stage') or not training):
                 # (with a weight gradient to come, the transformed input is kept for it)
                 h2, v2 = wino_fwd(h1, nhwc(W2), d2, s2, b2, True,
                                   keep_v=training and bool(ctx.needs_input_grad[4 + pos + 3]),

@@ -17,7 +17,7 @@ from test_gpu_model import _build, _BLOCKS, _rel, H, W   # noqa: E402
 def run(n_layers):
     dev = torch.device('cuda:0')
     model, chain, imgs, bboxes, labels, masks = _build(dev, n_layers)
-    damp = float(os.environ.get('HEAD_DAMP', '1'))
+    damp = float(os.environ.get('HEAD_DAMP', '1'))   # experiment: damp res5's residual branches
     if damp != 1:
         with torch.no_grad():
             for name, m in model.head.res5.named_modules():
@@ -86,8 +86,9 @@ def run(n_layers):
 
 if __name__ == '__main__':
     from chainer_mask_rcnn_amd.functions import conv as C
-    for use, fw, blk in ((True, False, ()), (True, True, ())):
-        C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD, C.WINOGRAD_TRAIN_FORWARD_BLOCKS = use, fw, blk
-        print('Winograd backward:', use, ' Winograd train forward:', fw, blk)
+    C.WINOGRAD_MIN_WORK = 1 << 24          # route the small test models like the full-size ones
+    for use, fw in ((False, False), (True, False), (True, 'conv2d'), (True, True)):
+        C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD = use, fw
+        print('Winograd backward:', use, ' Winograd forward in the train step:', fw)
         for n in (50, 101):
             run(n)
