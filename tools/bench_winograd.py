@@ -2,7 +2,8 @@
 Winograd F(4x4,3x3) route vs the implicit-GEMM route.  usage: python tools/bench_winograd.py [N C K H]"""
 import sys
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chainer_mask_rcnn_amd import _lib
 from chainer_mask_rcnn_amd.functions import conv as C
 from chainer_mask_rcnn_amd.functions._layout import nhwc, empty_nhwc
