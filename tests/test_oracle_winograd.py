@@ -35,3 +35,24 @@ def test_three_passes_equal_the_direct_convolution(shape):
     np.testing.assert_allclose(W.conv3x3_fwd(x, w), y_ref, **tol)
     np.testing.assert_allclose(W.conv3x3_dgrad(g, w), gx_ref, **tol)
     np.testing.assert_allclose(W.conv3x3_wgrad(x, g), gw_ref, **tol)
+
+
+def test_route_selection_for_the_benchmark_shapes():
+    """functions/conv.py:uses_winograd — which layers of the BASELINE configurations take the
+    Winograd route (host logic, no GPU): the RoI head's res5 3x3 and the RPN conv1 in both
+    workloads, res4 only at the inference batch size, nothing narrower than 256 channels, nothing
+    that is not 3x3 / stride 1 / pad 1."""
+    from chainer_mask_rcnn_amd.functions import conv as C
+
+    def d(N, Cc, H, Wd, K, k=3, s=1, p=1):
+        return C.make_desc((N, Cc, H, Wd), (K, Cc, k, k), s, p)
+    assert C.uses_winograd(d(1024, 512, 7, 7, 512))          # res5, train (1024 sampled RoIs)
+    assert C.uses_winograd(d(1000, 512, 7, 7, 512))          # res5, inference (per image)
+    assert C.uses_winograd(d(2, 1024, 50, 84, 1024))         # RPN conv1, train
+    assert C.uses_winograd(d(8, 1024, 64, 64, 1024))         # RPN conv1, inference
+    assert C.uses_winograd(d(8, 256, 65, 65, 256))           # res4, inference batch
+    assert not C.uses_winograd(d(2, 256, 50, 84, 256))       # res4, train batch: too little work
+    assert not C.uses_winograd(d(2, 128, 100, 167, 128))     # res3: narrow
+    assert not C.uses_winograd(d(2, 64, 200, 334, 64))       # res2
+    assert not C.uses_winograd(d(1024, 512, 7, 7, 512, k=1, p=0))
+    assert not C.uses_winograd(d(2, 512, 28, 28, 512, s=2))
