@@ -25,6 +25,7 @@
 // valid as long as A and B agree).
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -155,10 +156,24 @@ struct GemmParams {
     // winograd.hip): floats between consecutive problems of A, B and C.  The extents above
     // are then per problem.
     int64_t batch_a, batch_b, batch_c;
+    // Start-up stagger (launch_kernel_m): the dispatcher places workgroup b, b + 256, b + 512 on
+    // the same CU, and co-resident workgroups that start together stay in lockstep for hundreds
+    // of microseconds — they stage, hit their barriers and run their epilogues at the same time,
+    // and the matrix pipe idles meanwhile.  Workgroup b of the first stagger_slots x 256 sleeps
+    // (b / 256) x stagger_cycles shader cycles before its first load, so the phases interleave.
+    // Placement only decides how well this works, never the result.
+    int stagger_slots, stagger_cycles;
 };
 
 #ifdef MRCNN_GEMM_TRACE
 __device__ unsigned long long g_trace[64 * 4 * 64 * 5];
+#endif
+#ifdef MRCNN_GEMM_CLOCKPROBE
+// developer instrumentation: per workgroup (shader-clock, 100 MHz reference clock) stamps at the
+// start and the end of the kernel body + the XCC / CU it ran on (tools/exp/clock_probe.py)
+constexpr int kProbeSlots = 16384;
+__device__ unsigned long long g_probe[kProbeSlots * 5];
+__device__ unsigned long long g_probe2[kProbeSlots * 8];   // main loop entry / exit (s_memrealtime)
 #endif
 
 // GEMM row -> (image, position) under the block-position-major order of GemmParams::perm_n
@@ -215,12 +230,18 @@ __device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, unsigned off, 
 {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
 }
+#ifndef MRCNN_GEMM_STORE_AUX
+#define MRCNN_GEMM_STORE_AUX 0
+#endif
 __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v)
 {
     u32x4 u;
     u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y);
     u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 0);
+#ifdef MRCNN_DBG_NOSTORE      // ablation: every wide store takes the dropped (out-of-range) path
+    off = kOOB;
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, MRCNN_GEMM_STORE_AUX);
 }
 __device__ __forceinline__ float4 relu_mask(float4 v, float4 y)
 {
@@ -253,6 +274,26 @@ conv_gemm_kernel(const GemmParams p)
 
     float (*smem)[C_::A_FLOATS + C_::B_FLOATS] = smem_all[0];
     const int tid = threadIdx.x;
+#ifdef MRCNN_GEMM_CLOCKPROBE
+    const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long probe_r0 = __builtin_amdgcn_s_memrealtime();
+    struct ProbeEnd {
+        unsigned long long c0, r0; int tid;
+        __device__ ~ProbeEnd() {
+            if (tid != 0) return;
+            const unsigned slot = blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y;
+            if (slot >= (unsigned)kProbeSlots) return;
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long *q = g_probe + (size_t)slot * 5;
+            q[0] = c0; q[1] = r0;
+            q[2] = __builtin_amdgcn_s_memtime(); q[3] = __builtin_amdgcn_s_memrealtime();
+            q[4] = ((unsigned long long)xcc << 32) | hw;
+        }
+    } probe_end = {probe_c0, probe_r0, tid};
+#endif
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -292,7 +333,20 @@ conv_gemm_kernel(const GemmParams p)
     constexpr int KC_C4 = BK / 4, KC_RPP = 256 / KC_C4;   // float4 per row, rows per pass
     const int kc_row = tid / KC_C4, kc_c4 = tid % KC_C4;
     int a_n[AV], a_y[AV], a_x[AV];     // FWD/DGRAD: pixel coords of each A row
-    if (MODE != WGRAD) {
+    // 1x1 / stride 1 / pad 0 forward-form launches (two thirds of the RoI head's GEMMs): GEMM row
+    // m IS pixel m of the gathered tensor — no (image, y, x) decomposition, i.e. none of the
+    // eight integer divisions of the general set-up
+    const bool pointwise = FWDLIKE && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 &&
+                           p.perm_n == 0 && !p.stem && p.gp == p.sh && p.gq == p.sw;   // uniform
+    if (MODE != WGRAD && pointwise) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int m = m0 + kc_row + KC_RPP * i;
+            a_n[i] = m < p.M ? m : 0;          // (pixel index; folded into a_base below)
+            a_x[i] = 0;
+            a_y[i] = m < p.M ? 0 : -(1 << 28);
+        }
+    } else if (MODE != WGRAD) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int m = m0 + kc_row + KC_RPP * i;
@@ -397,6 +451,16 @@ conv_gemm_kernel(const GemmParams p)
         nslices = max(0, min(nslices - kt0, split_len));
     }
 
+    if (p.stagger_cycles > 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned slot = lin >> 8;
+        if (slot > 0 && slot < (unsigned)p.stagger_slots) {          // workgroup-uniform
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            const unsigned long long wait = (unsigned long long)slot * (unsigned)p.stagger_cycles;
+            while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+
     float4 ra[AV], rb[BV];
     float4 rm[HAS_MASK ? AV : 1];
     float4 rscale = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -411,7 +475,8 @@ conv_gemm_kernel(const GemmParams p)
     if (MODE != WGRAD) {
 #pragma unroll
         for (int i = 0; i < AV; ++i)
-            a_base[i] = (unsigned)(((a_n[i] * p.sh + a_y[i]) * p.sw + a_x[i]) * p.lda + kc_c4 * 4);
+            a_base[i] = pointwise ? (unsigned)(a_n[i] * p.lda + kc_c4 * 4)
+                                  : (unsigned)(((a_n[i] * p.sh + a_y[i]) * p.sw + a_x[i]) * p.lda + kc_c4 * 4);
         if (FWDLIKE) {
 #pragma unroll
             for (int i = 0; i < BV; ++i) {
@@ -637,6 +702,10 @@ conv_gemm_kernel(const GemmParams p)
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
     };
 
+#ifdef MRCNN_GEMM_CLOCKPROBE
+    const unsigned probe_slot = blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y;
+    if (tid == 0 && probe_slot < (unsigned)kProbeSlots) g_probe2[probe_slot * 8] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (nslices > 0) {
         load_slice(0);
         store_slice(0);
@@ -646,12 +715,16 @@ conv_gemm_kernel(const GemmParams p)
         // ~40 % of a slice issuing MFMAs and ~60 % staging, so three interleaved waves are
         // needed to keep the pipe full; two barriers per slice instead of one.
         for (int kt = 0; kt < nslices; ++kt) {
+#ifndef MRCNN_DBG_NOSTAGE     // ablation: MFMA + fragment reads only (results are garbage)
             if (kt > 0) {
                 __syncthreads();          // every wave is done reading the stage
                 store_slice(0);
             }
             __syncthreads();
+#endif
+#ifndef MRCNN_DBG_NOGLOBAL    // ablation: no global loads in the loop (results are garbage)
             if (kt + 1 < nslices) load_slice(kt + 1);
+#endif
             compute(0);
         }
     } else {
@@ -686,6 +759,9 @@ conv_gemm_kernel(const GemmParams p)
 #undef TRACE_STAMP
     }
 
+#ifdef MRCNN_GEMM_CLOCKPROBE
+    if (tid == 0 && probe_slot < (unsigned)kProbeSlots) g_probe2[probe_slot * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---------------- epilogue ------------------------------------------------------
     // Per 32x32 MFMA tile: compute the 16 element offsets, issue every auxiliary load
     // (residual / accumulate / shortcut gradient) back to back, then combine and store.
@@ -700,12 +776,17 @@ conv_gemm_kernel(const GemmParams p)
     const __amdgpu_buffer_rsrc_t rResG = make_rsrc(p.res_g, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rResY = make_rsrc(p.res_y, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rOutM = make_rsrc(p.out_mask_y, p.c_bytes);
+#ifdef MRCNN_DBG_PLAIN_EPI     // ablation: no fused epilogue arithmetic at all (plain stores)
+    constexpr bool f_bias = false, f_aff = false, f_res = false, f_relu = false, f_acc = false;
+    constexpr bool f_resg = false, f_resy = false, f_outm = false;
+#else
     const bool f_bias = (e_flags & MRCNN_EPI_BIAS) != 0, f_aff = (e_flags & MRCNN_EPI_AFFINE) != 0;
     const bool f_res = (e_flags & MRCNN_EPI_RESIDUAL) != 0, f_relu = (e_flags & MRCNN_EPI_RELU) != 0;
     const bool f_acc = (e_flags & MRCNN_EPI_ACCUM) != 0;
     const bool f_resg = MODE != WGRAD && !tail && p.res_g != nullptr;
     const bool f_resy = f_resg && p.res_y != nullptr;
     const bool f_outm = MODE != WGRAD && !tail && p.out_mask_y != nullptr;
+#endif
     constexpr int EG = 8;       // accumulator rows handled per batch of auxiliary loads
 
     if constexpr (MODE == FWD && TM == 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
@@ -720,6 +801,12 @@ conv_gemm_kernel(const GemmParams p)
         constexpr int NK = 32 / RPI;                // passes per 32-row half
         constexpr int QG = TM == 2 ? 4 : 2;         // passes whose loads are in flight together
         __syncthreads();                            // every wave is done with the K loop's LDS
+#ifdef MRCNN_GEMM_CLOCKPROBE
+#define PROBE2(k) if (tid == 0 && probe_slot < (unsigned)kProbeSlots) g_probe2[probe_slot * 8 + (k)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define PROBE2(k)
+#endif
+        PROBE2(2)
         float *ep = &smem_all[0][0][0] + wave * (32 * LDW);
         const int c4 = lane % F4, r_in = lane / F4;
         const int col = n0 + wn * CW + c4 * 4;
@@ -733,80 +820,122 @@ conv_gemm_kernel(const GemmParams p)
                 if (p.shift) shift4 = *reinterpret_cast<const float4 *>(p.shift + col);
             }
         }
+        // The combine step is specialised at compile time for the flag combinations the model
+        // launches (F >= 0: bit k of F = flag k below), selected by ONE workgroup-uniform switch:
+        // with run-time flags every element went through a chain of eight add / select pairs
+        // (about 120 VALU instructions per 16-byte store, a quarter of a 16-slice tile's
+        // lifetime); F = -1 keeps that generic path for any other combination.  The operation
+        // order per element is the same in every instantiation, so results are bit-identical.
+        enum { C_BIAS = 1, C_AFF = 2, C_RES = 4, C_RELU = 8, C_ACC = 16, C_RESG = 32, C_RESY = 64,
+               C_OUTM = 128 };
+        auto run = [&](auto tag) {
+            constexpr int F = decltype(tag)::value;
+            const bool c_bias = F >= 0 ? (F & C_BIAS) != 0 : f_bias;
+            const bool c_aff = F >= 0 ? (F & C_AFF) != 0 : f_aff;
+            const bool c_res = F >= 0 ? (F & C_RES) != 0 : f_res;
+            const bool c_relu = F >= 0 ? (F & C_RELU) != 0 : f_relu;
+            const bool c_acc = F >= 0 ? (F & C_ACC) != 0 : f_acc;
+            const bool c_resg = F >= 0 ? (F & C_RESG) != 0 : f_resg;
+            const bool c_resy = F >= 0 ? (F & C_RESY) != 0 : f_resy;
+            const bool c_outm = F >= 0 ? (F & C_OUTM) != 0 : f_outm;
+            const bool natural = F >= 0 || !(p.perm_n > 0 && !slab_rows);   // F >= 0: natural row order
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    ep[((e & 3) + 8 * (e >> 2) + 4 * lk) * LDW + j * 32 + li] = acc[i][j][e];
-            // same wave writes and reads: LDS operations of a wave execute in order
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (int e = 0; e < 16; ++e)
+                        ep[((e & 3) + 8 * (e >> 2) + 4 * lk) * LDW + j * 32 + li] = acc[i][j][e];
+                // same wave writes and reads: LDS operations of a wave execute in order
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (i == 0) { PROBE2(3) } else { PROBE2(5) }
 #pragma unroll
-            for (int kg = 0; kg < NK; kg += QG) {
-                unsigned off[QG];
-                float4 v[QG], a0[QG], a1[QG], a2[QG], a3[QG];
+                for (int kg = 0; kg < NK; kg += QG) {
+                    unsigned off[QG];
+                    float4 v[QG], a0[QG], a1[QG], a2[QG], a3[QG];
 #pragma unroll
-                for (int q = 0; q < QG; ++q) {
-                    const int r = (kg + q) * RPI + r_in;
-                    v[q] = *reinterpret_cast<const float4 *>(ep + r * LDW + c4 * 4);
-                    const int row = m0 + wm * (32 * TM) + i * 32 + r;
-                    int o;
-                    if (p.perm_n > 0 && !slab_rows) {
-                        const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
-                        o = pr.n < p.perm_n ? (pr.n * (p.gp * p.gq) + pr.pos) * p.ldc + col : -1;
-                    } else {
-                        o = (row - e_row0) * e_ldc + col;
+                    for (int q = 0; q < QG; ++q) {
+                        const int r = (kg + q) * RPI + r_in;
+                        v[q] = *reinterpret_cast<const float4 *>(ep + r * LDW + c4 * 4);
+                        const int row = m0 + wm * (32 * TM) + i * 32 + r;
+                        int o;
+                        if (!natural) {
+                            const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
+                            o = pr.n < p.perm_n ? (pr.n * (p.gp * p.gq) + pr.pos) * p.ldc + col : -1;
+                        } else {
+                            o = (row - e_row0) * e_ldc + col;
+                        }
+                        off[q] = (col_ok && row < p.M && o >= 0) ? 4u * (unsigned)o : kOOB;
                     }
-                    off[q] = (col_ok && row < p.M && o >= 0) ? 4u * (unsigned)o : kOOB;
-                }
-                if (f_res) {
+                    if (c_res) {
 #pragma unroll
-                    for (int q = 0; q < QG; ++q) a0[q] = bload4(rRes, off[q]);
-                }
-                if (f_acc) {
-#pragma unroll
-                    for (int q = 0; q < QG; ++q) a1[q] = bload4(rC, off[q]);
-                }
-                if (f_resg) {
-#pragma unroll
-                    for (int q = 0; q < QG; ++q) a0[q] = bload4(rResG, off[q]);
-                }
-                if (f_resy) {
-#pragma unroll
-                    for (int q = 0; q < QG; ++q) a2[q] = bload4(rResY, off[q]);
-                }
-                if (f_outm) {
-#pragma unroll
-                    for (int q = 0; q < QG; ++q) a3[q] = bload4(rOutM, off[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < QG; ++q) {
-                    float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-                    const float b[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
-                    const float sc[4] = {scale4.x, scale4.y, scale4.z, scale4.w};
-                    const float sh[4] = {shift4.x, shift4.y, shift4.z, shift4.w};
-                    const float r0[4] = {a0[q].x, a0[q].y, a0[q].z, a0[q].w};
-                    const float r1[4] = {a1[q].x, a1[q].y, a1[q].z, a1[q].w};
-                    const float r2[4] = {a2[q].x, a2[q].y, a2[q].z, a2[q].w};
-                    const float r3[4] = {a3[q].x, a3[q].y, a3[q].z, a3[q].w};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float y = x[t];
-                        if (f_bias) y += b[t];
-                        if (f_aff) y = y * sc[t] + sh[t];
-                        if (f_res) y += r0[t];
-                        if (f_acc) y += r1[t];
-                        if (f_resy) y += r2[t] > 0.f ? r0[t] : 0.f;
-                        else if (f_resg) y += r0[t];
-                        if (f_relu) y = fmaxf(y, 0.f);
-                        if (f_outm) y = r3[t] > 0.f ? y : 0.f;
-                        x[t] = y;
+                        for (int q = 0; q < QG; ++q) a0[q] = bload4(rRes, off[q]);
                     }
-                    bstore4(rC, off[q], make_float4(x[0], x[1], x[2], x[3]));
+                    if (c_acc) {
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) a1[q] = bload4(rC, off[q]);
+                    }
+                    if (c_resg) {
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) a0[q] = bload4(rResG, off[q]);
+                    }
+                    if (c_resy) {
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) a2[q] = bload4(rResY, off[q]);
+                    }
+                    if (c_outm) {
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) a3[q] = bload4(rOutM, off[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) {
+                        float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                        const float b[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+                        const float sc[4] = {scale4.x, scale4.y, scale4.z, scale4.w};
+                        const float sh[4] = {shift4.x, shift4.y, shift4.z, shift4.w};
+                        const float r0[4] = {a0[q].x, a0[q].y, a0[q].z, a0[q].w};
+                        const float r1[4] = {a1[q].x, a1[q].y, a1[q].z, a1[q].w};
+                        const float r2[4] = {a2[q].x, a2[q].y, a2[q].z, a2[q].w};
+                        const float r3[4] = {a3[q].x, a3[q].y, a3[q].z, a3[q].w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float y = x[t];
+                            if (c_bias) y += b[t];
+                            if (c_aff) y = y * sc[t] + sh[t];
+                            if (c_res) y += r0[t];
+                            if (c_acc) y += r1[t];
+                            if (c_resy) y += r2[t] > 0.f ? r0[t] : 0.f;
+                            else if (c_resg) y += r0[t];
+                            if (c_relu) y = fmaxf(y, 0.f);
+                            if (c_outm) y = r3[t] > 0.f ? y : 0.f;
+                            x[t] = y;
+                        }
+                        bstore4(rC, off[q], make_float4(x[0], x[1], x[2], x[3]));
+                    }
                 }
+                if (i == 0) { PROBE2(4) } else { PROBE2(6) }
             }
+        };
+        const int combo = (f_bias ? C_BIAS : 0) | (f_aff ? C_AFF : 0) | (f_res ? C_RES : 0) |
+                          (f_relu ? C_RELU : 0) | (f_acc ? C_ACC : 0) | (f_resg ? C_RESG : 0) |
+                          (f_resy ? C_RESY : 0) | (f_outm ? C_OUTM : 0);
+        const bool permuted = p.perm_n > 0 && !slab_rows;
+#define MRCNN_EPI_CASE(F) case (F): run(std::integral_constant<int, (F)>()); break;
+        switch (permuted ? -1 : combo) {       // workgroup-uniform
+            MRCNN_EPI_CASE(0)
+            MRCNN_EPI_CASE(C_AFF)
+            MRCNN_EPI_CASE(C_AFF | C_RELU)
+            MRCNN_EPI_CASE(C_AFF | C_RES | C_RELU)
+            MRCNN_EPI_CASE(C_BIAS)
+            MRCNN_EPI_CASE(C_BIAS | C_RELU)
+            MRCNN_EPI_CASE(C_AFF | C_OUTM)
+            MRCNN_EPI_CASE(C_RESG | C_OUTM)
+            MRCNN_EPI_CASE(C_RESG)
+            MRCNN_EPI_CASE(C_ACC | C_OUTM)
+            MRCNN_EPI_CASE(C_ACC)
+        default: run(std::integral_constant<int, -1>()); break;
         }
+#undef MRCNN_EPI_CASE
         return;
     }
 #pragma unroll
@@ -999,9 +1128,34 @@ constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
 int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM launch (lowers
                        // the resident workgroups per CU for co-residency experiments)
 
+int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal start-up stagger; 0 = off)
+int g_stagger_min_rounds = 2;
+
 template <int TM, int TN, int MODE, bool MASKED>
-void launch_kernel_m(const GemmParams &p, int64_t tiles, int splits, hipStream_t s, int batch = 1)
+void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_t s, int batch = 1)
 {
+    GemmParams p = p0;
+    {
+        // resident workgroups per CU of this instantiation (registers / LDS, see min_blocks)
+        const int slots = single_buffered(TM, MODE, MASKED) ? (TM == 2 ? 3 : 6) : (TM == 2 ? 2 : 4);
+        const int64_t wgs = tiles * splits * batch;
+        // K slices one workgroup walks and the matrix-pipe cycles of one of its waves per slice
+        const int64_t slices = MODE == WGRAD ? mrcnn::ceil_div(p.split_len, BK)
+                               : (p.split_len > 0 ? p.split_len
+                                                  : (int64_t)p.R * p.S * mrcnn::ceil_div(p.stem ? 32 : p.Kc, BK));
+        const int64_t slice_cycles = 4 * TM * TN * (BK / 8) * 64;
+        p.stagger_slots = 0; p.stagger_cycles = 0;
+        if (g_stagger > 0 && wgs >= 256ll * slots) {
+            int64_t cyc;
+            if (wgs >= (int64_t)g_stagger_min_rounds * 256 * slots)
+                cyc = slices * slice_cycles;       // a third (1 / slots) of a tile's lifetime
+            else
+                cyc = slice_cycles + 512;          // one round only: interleave the slice phases
+            cyc = cyc * g_stagger / 100;
+            p.stagger_slots = slots;
+            p.stagger_cycles = (int)std::min<int64_t>(cyc, 1 << 20);
+        }
+    }
     if constexpr (MODE == WGRAD && !MASKED) {
         if (p.perm_n > 0) {
             hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
@@ -1337,6 +1491,22 @@ int wgrad_splits(int64_t tiles, int64_t pixels, int64_t slots)
 
 }  // namespace
 
+#ifdef MRCNN_GEMM_CLOCKPROBE
+extern "C" int mrcnn_gemm_probe_read(unsigned long long *host, int n)
+{
+    MRCNN_HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * n));
+    void *dptr = nullptr;
+    MRCNN_HIP_TRY(hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_probe)));
+    MRCNN_HIP_TRY(hipMemset(dptr, 0, sizeof(g_probe)));      // ready for the next pass
+    return 0;
+}
+extern "C" int mrcnn_gemm_probe2_read(unsigned long long *host, int n)
+{
+    MRCNN_HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe2), sizeof(unsigned long long) * n));
+    return 0;
+}
+#endif
+
 #ifdef MRCNN_GEMM_TRACE
 extern "C" int mrcnn_gemm_trace_read(unsigned long long *host, int n)
 {
@@ -1376,6 +1546,14 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "small_m_split") == 0) {
         g_small_m_split = value;
+        return 0;
+    }
+    if (strcmp(name, "stagger") == 0) {
+        g_stagger = value;
+        return 0;
+    }
+    if (strcmp(name, "stagger_min_rounds") == 0) {
+        g_stagger_min_rounds = value;
         return 0;
     }
     MRCNN_REQUIRE(false, "set_tuning: unknown option '%s'", name);

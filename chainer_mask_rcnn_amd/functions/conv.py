@@ -428,20 +428,26 @@ _wino_u_cache = {}
 
 
 def weights_changed():
-    """Parameters were written outside torch's version tracking (the SGD kernel updates the flat
-    arena through a raw pointer): drop every cached transformed filter."""
+    """Public invalidation call: parameters were written outside torch's version tracking — the
+    SGD kernel updates the flat arena through a raw pointer; user code that writes through
+    ``p.data`` (``p.data.copy_``, ``np.copyto`` on a mapped array, ``load_state_dict(assign=
+    True)``) does not bump ``_version`` either.  Drops every cached transformed filter; the
+    serializers call it, and so must any other out-of-band writer."""
     _wino_u_cache.clear()
 
 
 def _cached_filter_transform(W, Wc, d):
     key = id(W)
     hit = _wino_u_cache.get(key)
-    if hit is not None and hit[0] is W and hit[1] == W._version and hit[2].device == Wc.device:
+    # identity + version + storage address: ``p.data = t`` / ``assign=True`` loads swap the
+    # storage without touching the version counter
+    if hit is not None and hit[0] is W and hit[1] == W._version and hit[3] == W.data_ptr() \
+            and hit[2].device == Wc.device:
         return hit[2]
     u = torch.empty((_lib.load().mrcnn_conv3x3_wino_u_bytes(ctx_desc(d)) // 4,),
                     dtype=torch.float32, device=Wc.device)
     _lib.call('mrcnn_conv3x3_wino_filter', ctx_desc(d), _lib.ptr(Wc), _lib.ptr(u), _lib.stream_ptr())
-    _wino_u_cache[key] = (W, W._version, u)
+    _wino_u_cache[key] = (W, W._version, u, W.data_ptr())
     return u
 
 

@@ -47,9 +47,15 @@ def save_npz(path, model):
 def load_npz(path, model, strict=True):
     """Copy a chainer `.npz` snapshot into `model` (shapes must match, as `np.copyto` in the
     reference's converter would require)."""
+    from . import optimizers
+    from .functions import conv
+    # a held-back weight gradient + SGD slice of the previous step must land BEFORE the snapshot
+    # is copied in (it would otherwise update the freshly loaded head weights)
+    optimizers.flush_all()
     data = np.load(path)
     fused = _fused_parts(model)
     used = set()
+    conv.weights_changed()                 # cached transformed filters of inference calls
     with torch.no_grad():
         for name, p in model.named_parameters():
             owner, leaf = name.rsplit('.', 1)

@@ -28,6 +28,12 @@ def dev():
     # the Winograd route (a performance heuristic, functions/conv.py:uses_winograd) so that the
     # model-level parity tests run the SAME route as the full-size configurations — the RoI
     # head's 3x3 layers and the RPN conv1 on Winograd backward / inference forward.
+    # Restored at session end so that CPU tests of the routing policy sharing this process see
+    # the shipped default whatever the test order.
     from chainer_mask_rcnn_amd.functions import conv
+    saved = conv.WINOGRAD_MIN_WORK
     conv.WINOGRAD_MIN_WORK = 1 << 24
-    return torch.device('cuda:0')
+    try:
+        yield torch.device('cuda:0')
+    finally:
+        conv.WINOGRAD_MIN_WORK = saved
