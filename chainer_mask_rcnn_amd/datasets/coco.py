@@ -126,51 +126,55 @@ class COCOInstanceSegmentationDataset(object):
     def get_example(self, i):
         import PIL.Image
         img_id = self.img_ids[i]
-        anns = self._anns_of_img[img_id]
-        img = np.asarray(PIL.Image.open(self.img_fname.format(img_id)))
+        # Every file ends up as HxWx3 uint8 RGB whatever its JPEG colour model: grayscale is
+        # replicated (the reference's cv2.COLOR_GRAY2RGB), CMYK / palette / alpha files go through
+        # PIL's colour conversion (skimage.io.imread, which the reference calls, does the same);
+        # slicing the first three planes of a CMYK array would be wrong pixel data.
+        with PIL.Image.open(self.img_fname.format(img_id)) as f:
+            img = np.asarray(f if f.mode in ('L', 'RGB') else f.convert('RGB'))
         if img.ndim == 2:
-            img = np.repeat(img[:, :, None], 3, axis=2)       # cv2.COLOR_GRAY2RGB
-        elif img.shape[2] == 4:
-            img = img[:, :, :3]
-        example = self._annotations_to_example(anns, img.shape[0], img.shape[1])
+            img = np.repeat(img[:, :, None], 3, axis=2)
+        example = self._annotations_to_example(self._anns_of_img[img_id], img.shape[0], img.shape[1])
         return tuple([img] + example)
 
-    def _annotations_to_example(self, anns, height, width):
-        import PIL.Image
-        import PIL.ImageDraw
-        bboxes, labels, masks, crowds, areas = [], [], [], [], []
+    # -- annotations -> (bboxes, labels, masks[, crowds][, areas]) -------------------------------
+    # Contract of the reference's datasets/coco.py:123-176 (pinned by tests/golden/coco_example.npz):
+    # an instance is kept when it has a segmentation, is not a crowd region (unless use_crowd) and
+    # — for run-length masks — decodes to the image size; its box is the tight box of its mask.
+    @staticmethod
+    def _rasterise(segmentation, height, width):
+        """Polygon list or COCO RLE dict -> (height, width) bool mask, or None when a run-length
+        mask does not match the image (malformed minival annotations are dropped)."""
+        if isinstance(segmentation, list):
+            import PIL.Image
+            import PIL.ImageDraw
+            canvas = PIL.Image.new('L', (width, height), 0)
+            pen = PIL.ImageDraw.Draw(canvas)
+            for ring in segmentation:
+                pts = np.asarray(ring).reshape(-1, 2)
+                pen.polygon(xy=list(map(tuple, pts)), outline=1, fill=1)
+            return np.asarray(canvas) == 1
+        decoded = rle_decode(segmentation, height, width)
+        return decoded == 1 if decoded.shape == (height, width) else None
+
+    def _kept_instances(self, anns, height, width):
         for ann in anns:
-            if 'segmentation' not in ann:
+            if 'segmentation' not in ann or (ann['iscrowd'] == 1 and not self._use_crowd):
                 continue
-            if not self._use_crowd and ann['iscrowd'] == 1:
-                continue
-            class_id = self.cat_id_to_class_id[ann['category_id']]
-            if isinstance(ann['segmentation'], list):
-                # polygon
-                mask = PIL.Image.fromarray(np.zeros((height, width), dtype=np.uint8))
-                for seg in ann['segmentation']:
-                    xy = np.array(seg).reshape((-1, 2))
-                    xy = [tuple(xy_i) for xy_i in xy]
-                    PIL.ImageDraw.Draw(mask).polygon(xy=xy, outline=1, fill=1)
-                mask = np.asarray(mask)
-            else:
-                # run-length mask
-                mask = rle_decode(ann['segmentation'], height, width)
-                # FIXME (reference): some of minival annotations are malformed.
-                if mask.shape != (height, width):
-                    continue
-            mask = mask == 1
-            bboxes.append(mask_to_bbox(mask))  # y1, x1, y2, x2
-            masks.append(mask)
-            labels.append(class_id)
-            crowds.append(ann['iscrowd'])
-            areas.append(ann['area'])
-        bboxes = np.asarray(bboxes, dtype=np.float32).reshape((-1, 4))
-        labels = np.asarray(labels, dtype=np.int32)
-        masks = np.asarray(masks, dtype=np.int32).reshape((-1, height, width))
-        example = [bboxes, labels, masks]
+            inst = self._rasterise(ann['segmentation'], height, width)
+            if inst is not None:
+                yield ann, inst
+
+    def _annotations_to_example(self, anns, height, width):
+        kept = list(self._kept_instances(anns, height, width))
+        col = lambda fn, dt: np.asarray([fn(a, m) for a, m in kept], dtype=dt)
+        example = [
+            col(lambda a, m: mask_to_bbox(m), np.float32).reshape((-1, 4)),       # y1, x1, y2, x2
+            col(lambda a, m: self.cat_id_to_class_id[a['category_id']], np.int32),
+            col(lambda a, m: m, np.int32).reshape((-1, height, width)),
+        ]
         if self._return_crowd:
-            example.append(np.asarray(crowds, dtype=np.int32))
+            example.append(col(lambda a, m: a['iscrowd'], np.int32))
         if self._return_area:
-            example.append(np.asarray(areas, dtype=np.float32))
+            example.append(col(lambda a, m: a['area'], np.float32))
         return example

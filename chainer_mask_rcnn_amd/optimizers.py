@@ -272,6 +272,22 @@ class MomentumSGD(object):
             # backward skipped the parameter): all ranks update everything, no host round trip
             written = [True] * len(written)
         held = set()
+        if deferred is not None and self.grad_sync is not None:
+            # Data parallel: a deferred parameter is in NO in-backward bucket (the bucket plan
+            # leaves it to reduce_deferred).  If its weight gradient was not actually held back
+            # this step (the in-place claim failed: gradient view dropped, parameter used twice,
+            # a route that bypasses _wgrad_raw), nothing would all-reduce it and the ranks would
+            # drift apart silently — fail loudly instead.
+            queued = set(j[3].data_ptr() for j in deferred.jobs)
+            missing = [i for i, p in enumerate(a.params)
+                       if id(p) in deferred.ids and p._grad_epoch == a.epoch
+                       and p.grad.data_ptr() not in queued]
+            if missing:
+                raise RuntimeError(
+                    'defer_weight_gradients: %d deferred parameter(s) received a gradient that was '
+                    'not held back (arena index %s); under data parallelism their gradients would '
+                    'never be all-reduced.  Defer only RoI-head convolution filters that are used '
+                    'once per step.' % (len(missing), missing[:4]))
         if deferred is not None and deferred.jobs:
             # parameters whose gradient kernels were held back: their slices are updated by
             # launch_pending(), after those kernels, in the next step's proposal window
