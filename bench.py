@@ -112,6 +112,41 @@ def stabilise_synthetic_weights(model):
                     m.bn4.W.fill_(0.5)
 
 
+def fg_saturated_sampler(base):
+    """Benchmark workload device (not product code): a ProposalTargetCreator whose candidate list
+    also holds jittered copies of every ground-truth box (IoU >= 0.5 with it), so that the sampler
+    reaches its foreground cap round(n_sample * pos_ratio) = 128 per image
+    (/root/reference/chainer_mask_rcnn/models/utils/proposal_target_creator.py:49-61,132-147) as
+    it does once the RPN of a real training run proposes the objects.  A random-init RPN on
+    synthetic images yields ~30 foreground RoIs per image, and the mask branch's work scales with
+    that count.  The jitter comes from a private RandomState: the global np.random stream is
+    consumed exactly as before."""
+    cls = type(base)
+
+    class FgSaturated(cls):
+        _jitter = np.random.RandomState(12345)
+
+        def _more(self, roi, bbox):
+            bbox = np.asarray(bbox, np.float32)
+            reps = int(np.ceil(1.5 * self.n_sample * self.pos_ratio / max(len(bbox), 1)))
+            b = np.repeat(bbox, reps, axis=0)
+            hw = np.stack([b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1)
+            d = self._jitter.uniform(-0.08, 0.08, (len(b), 4)).astype(np.float32)
+            jit = b + d * np.concatenate([hw, hw], 1)
+            roi = roi.detach().cpu().numpy() if isinstance(roi, torch.Tensor) else np.asarray(roi)
+            return np.concatenate([jit.astype(np.float32), roi.astype(np.float32)], 0)
+
+        def sample(self, roi, bbox, label, *a, **k):
+            return cls.sample(self, self._more(roi, bbox), bbox, label, *a, **k)
+
+        def __call__(self, roi, bbox, label, mask, *a, **k):
+            return cls.__call__(self, self._more(roi, bbox), bbox, label, mask, *a, **k)
+
+    obj = FgSaturated.__new__(FgSaturated)
+    obj.__dict__.update(base.__dict__)
+    return obj
+
+
 def profile_summary():
     from chainer_mask_rcnn_amd import _lib
     lib = _lib.load()
@@ -327,6 +362,12 @@ def main():
                          'over K pre-generated host batches with the image upload inside the '
                          'timed region (the reference converter uploads every iteration, '
                          'examples/train_common.py:219-225); 0 = skip')
+    ap.add_argument('--no-fg-capped', dest='fg_capped', action='store_false',
+                    help='skip the second measurement with the proposal sampler at its foreground cap')
+    ap.add_argument('--pipeline-examples', type=int, default=16,
+                    help='after the other measurements, time the same number of steps fed by the train '
+                         "loop's input pipeline (tools/train_loop.py) over this many synthetic decoded "
+                         'examples; 0 = skip')
     ap.add_argument('--defer-wgrad', type=int, default=5,
                     help='number of res5 weight gradients (a.conv2, a.conv1, a.conv3, a.conv4, b1.conv2, ...) held back into the '
                          "next step's proposal window (single-GPU runs; 0 = off)")
@@ -476,6 +517,70 @@ def main():
                               'timed region' % K,
                         loss=round(float(loss_r.item()), 5))
 
+    # ---- the same step with the proposal sampler at its 128-foreground cap ----------------------
+    fg_capped = None
+    n_fg_default = chain.last_targets.get('n_fg')
+    if args.fg_capped:
+        ptc0 = chain.proposal_target_creator
+        chain.proposal_target_creator = fg_saturated_sampler(ptc0)
+        for _ in range(max(2, args.warmup)):
+            step()
+        fence()
+        lib.mrcnn_profile_enable(3) if not args.no_profile else None    # count flops only
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_c = step()
+        fence()
+        el_c = max_over_ranks(time.perf_counter() - t0)
+        prof_c = {} if args.no_profile else profile_summary()
+        lib.mrcnn_profile_enable(0)
+        gf_c = sum(v['flops'] for k, v in prof_c.items() if k.startswith('conv_gemm')) / 1e9
+        fg_capped = dict(value=round(args.steps * args.batch * world / el_c, 3), unit='images/sec',
+                         ms_per_step=round(el_c / args.steps * 1e3, 3),
+                         fg_rois_per_image=chain.last_targets['n_fg'] / float(args.batch),
+                         executed_gemm_gflop_per_image=round(gf_c / args.steps / args.batch, 1) if gf_c else None,
+                         workload='same step, sampler saturated: jittered copies of the ground-truth '
+                                  'boxes join the proposals, so every image reaches the reference\'s '
+                                  'foreground cap (128 of 512 RoIs) as in a trained run',
+                         loss=round(float(loss_c.item()), 5))
+        chain.proposal_target_creator = ptc0
+
+    # ---- third measurement: the same step fed by the train loop's input pipeline ----------------
+    pipeline = None
+    if args.pipeline_examples > 0:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import train_loop as TL
+        import chainer_mask_rcnn_amd as cmr
+        data = TL.SyntheticInstances(args.pipeline_examples, seed=100 + rank,
+                                     height=int(round(args.height * 0.6)), width=int(round(args.width * 0.6)),
+                                     virtual_len=8192)
+        it = TL.SerialIterator(TL.TransformDataset(data, cmr.datasets.MaskRCNNTransform(model)), args.batch)
+        loop = TL.TrainLoop(it, chain, opt, device)
+        for _ in range(max(2, args.warmup)):
+            loop.step()
+        fence()
+        loop.host_seconds = dict(fetch=0., wait=0.)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_p = loop.step()
+        fence()
+        el_p = max_over_ranks(time.perf_counter() - t0)
+        loop.close()
+        pipeline = dict(value=round(args.steps * args.batch * world / el_p, 3), unit='images/sec',
+                        ms_per_step=round(el_p / args.steps * 1e3, 3),
+                        input='tools/train_loop.py: %d decoded uint8 HWC host examples (%dx%d, 8 '
+                              'instances, int32 masks) -> SerialIterator (shuffled, batch %d) -> '
+                              'MaskRCNNTransform (uint8 upload, device resize + mean + flip, host box / '
+                              'mask transform) -> concat_examples -> optimizer.update; the pipeline '
+                              'runs one batch ahead on a worker thread and its own stream, all of it '
+                              'inside the timed region'
+                              % (args.pipeline_examples, data.examples[0][0].shape[0],
+                                 data.examples[0][0].shape[1], args.batch),
+                        worker_ms_per_batch=round(loop.host_seconds['fetch'] / args.steps * 1e3, 2),
+                        worker_examples_ms_per_batch=round(loop.host_seconds.get('examples', 0.) / args.steps * 1e3, 2),
+                        step_waited_ms_per_batch=round(loop.host_seconds['wait'] / args.steps * 1e3, 2),
+                        loss=round(float(loss_p.detach().item()), 5))
+
     if rank == 0:
         global_batch = args.batch * world
         value = args.steps * global_batch / elapsed
@@ -493,6 +598,12 @@ def main():
                             peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                             frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                             traffic=pmc_traffic(name),
+                            # whole step: flops the GEMM kernels executed / step wall time / peak
+                            step_frac=round(gemm_gflop / 1e3 / elapsed / FP32_MFMA_PEAK_TFLOPS, 4),
+                            flops_counting='nominal per launch: 2*M*N*K with K = R*S*C_in (padding taps '
+                                           'of the 3x3 layers counted although ~18 % of their K slices '
+                                           'on 7x7 maps are skipped; Winograd launches count their '
+                                           'per-frequency GEMMs)',
                             avg_launch_us=round(d['total_ms'] * 1e3 / d['launches'], 2),
                             launches_per_step=d['launches'] / args.steps,
                             kernels={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
@@ -512,6 +623,9 @@ def main():
                         args.layers, '+RCCL all-reduce' if sync is not None else '',
                         args.batch, args.height, args.width, n_rois),
             input='resident', global_batch=global_batch, rois_per_image=n_rois // args.batch,
+            # foreground RoIs per image the sampler found on this synthetic batch (the mask branch
+            # and its executed flops scale with it; `fg_capped` below pins it at the reference's cap)
+            fg_rois_per_image=(n_fg_default / float(args.batch)) if n_fg_default is not None else None,
             deferred_weight_gradients=len(opt.deferred_params),
             parallelism='dp%d' % world,
             loss=round(loss_val, 5) if np.isfinite(loss_val) else None,
@@ -538,6 +652,10 @@ def main():
             data='synthetic', config=config, roofline=roofline)
         if rotating is not None:
             out['rotating_h2d'] = rotating
+        if pipeline is not None:
+            out['pipeline_h2d'] = pipeline
+        if fg_capped is not None:
+            out['fg_capped'] = fg_capped
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         emit_json(out)

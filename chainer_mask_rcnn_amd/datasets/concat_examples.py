@@ -35,6 +35,12 @@ def _concat_arrays(arrays, padding):
     if padding is None:
         return np.concatenate([a[None] for a in arrays])
     shape = (len(arrays),) + _pad_shape(arrays)
+    if all(a.shape == shape[1:] for a in arrays):
+        # nothing to pad (the usual case for a batch of equally sized images): one pass, no fill
+        out = np.empty(shape, dtype=first.dtype)
+        for i, a in enumerate(arrays):
+            out[i] = a
+        return out
     out = np.full(shape, padding, dtype=first.dtype)
     for i, a in enumerate(arrays):
         out[(i,) + tuple(slice(0, d) for d in a.shape)] = a

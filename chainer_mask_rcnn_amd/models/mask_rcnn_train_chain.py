@@ -155,7 +155,8 @@ class MaskRCNNTrainChain(torch.nn.Module):
         mark('losses queued')
         self.last_targets = {'sample_rois': sample_rois, 'gt_roi_labels': gt_roi_labels,
                              'gt_roi_masks': gt_roi_masks, 'gt_rpn_labels': gt_rpn_labels,
-                             'n_rois': int(sample_rois.shape[0])}
+                             'n_rois': int(sample_rois.shape[0]),
+                             'n_fg': getattr(self, '_last_n_fg', None)}   # host count, no read-back
         return loss
 
     def _forward_host_targets(self, features, img_size, scales, bboxes, labels, masks, anchor_h, mark):
@@ -209,6 +210,7 @@ class MaskRCNNTrainChain(torch.nn.Module):
             gt_roi_labels.append(gt_roi_label)
         up = lambda parts, dt: _upload(np.concatenate(parts, axis=0), dt, dev)
         gt_roi_labels_h = np.concatenate(gt_roi_labels, axis=0)
+        self._last_n_fg = int((gt_roi_labels_h > 0).sum())
         fg_rows = np.flatnonzero(gt_roi_labels_h > 0) if self.mask_branch_fg_only else np.zeros(0)
         cat = lambda parts: np.concatenate(parts, axis=0)
         sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels, fg_rows_d = _upload_many(
@@ -286,6 +288,7 @@ class MaskRCNNTrainChain(torch.nn.Module):
         sample_rois, sample_roi_indices = torch.cat(s_rois, 0), torch.cat(s_idx, 0)
         gt_roi_locs, gt_roi_labels = torch.cat(g_locs, 0), torch.cat(g_labels, 0)
         offs = np.concatenate([[0], np.cumsum([j['n'] for j in jobs])]).astype(int)
+        self._last_n_fg = int(sum(j['n_fg'] for j in jobs))
         fg_rows = np.concatenate([np.arange(offs[i], offs[i] + j['n_fg']) for i, j in enumerate(jobs)]) \
             if self.mask_branch_fg_only else np.zeros(0, np.int64)
         # ground-truth masks that live on the host: their 14x14 targets are built there (as in
