@@ -364,6 +364,8 @@ def main():
                          'examples/train_common.py:219-225); 0 = skip')
     ap.add_argument('--no-fg-capped', dest='fg_capped', action='store_false',
                     help='skip the second measurement with the proposal sampler at its foreground cap')
+    ap.add_argument('--no-device-targets', dest='device_targets', action='store_false',
+                    help='skip the measurement with the target creators on the device')
     ap.add_argument('--pipeline-examples', type=int, default=16,
                     help='after the other measurements, time the same number of steps fed by the train '
                          "loop's input pipeline (tools/train_loop.py) over this many synthetic decoded "
@@ -545,6 +547,28 @@ def main():
                          loss=round(float(loss_c.item()), 5))
         chain.proposal_target_creator = ptc0
 
+    # ---- the same step with the target creators' arithmetic on the device ----------
+    dev_targets = None
+    if args.device_targets:
+        masks_d = [torch.tensor(np.asarray(m) != 0, device=device).to(torch.uint8) for m in masks]
+        chain.device_targets = True
+        for _ in range(max(2, args.warmup)):
+            opt.update(chain, imgs_d, bboxes, labels, masks_d, scales)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_d = opt.update(chain, imgs_d, bboxes, labels, masks_d, scales)
+        fence()
+        el_d = max_over_ranks(time.perf_counter() - t0)
+        chain.device_targets = False
+        dev_targets = dict(value=round(args.steps * args.batch * world / el_d, 3), unit='images/sec',
+                           ms_per_step=round(el_d / args.steps * 1e3, 3),
+                           workload='same step, MaskRCNNTrainChain.device_targets = True: IoU matrices, '
+                                    'label rules, regression and 14x14 mask targets as HIP kernels, '
+                                    'ground-truth masks resident on the device (uint8); the np.random '
+                                    'draws stay on the host in the reference order (identical samples)',
+                           loss=round(float(loss_d.item()), 5))
+
     # ---- third measurement: the same step fed by the train loop's input pipeline ----------------
     pipeline = None
     if args.pipeline_examples > 0:
@@ -656,6 +680,8 @@ def main():
             out['pipeline_h2d'] = pipeline
         if fg_capped is not None:
             out['fg_capped'] = fg_capped
+        if dev_targets is not None:
+            out['device_targets'] = dev_targets
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         emit_json(out)

@@ -85,6 +85,7 @@ SIGNATURES = {
     'mrcnn_maxpool3x3s2p1_fwd': (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp]),
     'mrcnn_avgpool_fwd': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'mrcnn_avgpool_bwd': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    'mrcnn_head_tail_bwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'mrcnn_loss_workspace_bytes': (c_i64, [c_int]),
     'mrcnn_sigmoid_ce': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'mrcnn_mask_sigmoid_ce': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp,

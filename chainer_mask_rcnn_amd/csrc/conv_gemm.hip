@@ -40,7 +40,6 @@ constexpr int BK = MRCNN_GEMM_BK;
 #ifndef MRCNN_GEMM_SETPRIO
 #define MRCNN_GEMM_SETPRIO 0
 #endif
-constexpr bool SETPRIO = MRCNN_GEMM_SETPRIO != 0;
 // The forward-form kernel without mask staging fits 168 registers, so it runs with ONE LDS stage
 // (37 KB) and three workgroups per CU: a wave spends ~40 % of a K slice issuing MFMAs and
 // ~60 % staging (measured with s_memtime), so three interleaved waves per SIMD keep the pipe
@@ -70,7 +69,11 @@ constexpr bool single_buffered(int tm, int mode, bool masked)
 constexpr int min_blocks(int tm, int mode, bool masked)
 {
     if (!single_buffered(tm, mode, masked)) return MRCNN_GEMM_MINWAVES;
+#ifdef MRCNN_GEMM_BIGBLOCKS     // experiment: resident workgroups per CU of the 128x128 kernels
+    return tm == 2 ? MRCNN_GEMM_BIGBLOCKS : 6;
+#else
     return tm == 2 ? 3 : 6;
+#endif
 }
 // Experiment, off by default: the last workgroup of a wgrad tile to arrive sums the split-K
 // slabs inside the GEMM kernel instead of a separate reduce launch.  Correct (tools/
@@ -669,7 +672,8 @@ conv_gemm_kernel(const GemmParams p)
         const float *sb = smem[buf] + C_::A_FLOATS;
         float af[2][TM][4], bf[2][TN][4];
         load_frag(sa, sb, 0, af[0], bf[0]);
-        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+        if (MRCNN_GEMM_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (MRCNN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(0);   // staging phases run at 2
         // DS read instructions per K block (b32 pairs are merged into ds_read2_b32)
         constexpr int NR = (C_::A_KC ? TM : 2 * TM) + (C_::B_KC ? TN : 2 * TN);
         constexpr int NMFMA = 4 * TM * TN;
@@ -699,13 +703,15 @@ conv_gemm_kernel(const GemmParams p)
                 __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
             }
         }
-        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+        if (MRCNN_GEMM_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (MRCNN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(2);
     };
 
 #ifdef MRCNN_GEMM_CLOCKPROBE
     const unsigned probe_slot = blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y;
     if (tid == 0 && probe_slot < (unsigned)kProbeSlots) g_probe2[probe_slot * 8] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (MRCNN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(2);
     if (nslices > 0) {
         load_slice(0);
         store_slice(0);
@@ -714,19 +720,41 @@ conv_gemm_kernel(const GemmParams p)
         // one LDS stage (37 KB -> three workgroups per CU, three waves per SIMD): a wave spends
         // ~40 % of a slice issuing MFMAs and ~60 % staging, so three interleaved waves are
         // needed to keep the pipe full; two barriers per slice instead of one.
+#ifdef MRCNN_GEMM_TRACE
+        // developer instrumentation: per-phase s_memtime stamps of every wave of 64 workgroups
+        const unsigned tr_lin = blockIdx.x + blockIdx.y * gridDim.x;
+        unsigned long long *tr1 = g_trace + ((size_t)(tr_lin & 63) * 4 + wave) * 64 * 5;
+        const bool tr1_on = tr_lin >= 256 && tr_lin < 256 + 64 && lane == 0 && blockIdx.z == 0;
+#define TRACE1(slot)                                                             \
+    if (tr1_on && kt >= 4 && kt < 68) {                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
+        tr1[(kt - 4) * 5 + slot] = __builtin_amdgcn_s_memtime();                 \
+    }
+#else
+#define TRACE1(slot)
+#endif
         for (int kt = 0; kt < nslices; ++kt) {
+            TRACE1(0)
 #ifndef MRCNN_DBG_NOSTAGE     // ablation: MFMA + fragment reads only (results are garbage)
             if (kt > 0) {
                 __syncthreads();          // every wave is done reading the stage
+#ifdef MRCNN_GEMM_TRACE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                TRACE1(1)
                 store_slice(0);
             }
             __syncthreads();
 #endif
+            TRACE1(2)
 #ifndef MRCNN_DBG_NOGLOBAL    // ablation: no global loads in the loop (results are garbage)
             if (kt + 1 < nslices) load_slice(kt + 1);
 #endif
+            TRACE1(3)
             compute(0);
+            TRACE1(4)
         }
+#undef TRACE1
     } else {
         __syncthreads();
 #ifdef MRCNN_GEMM_TRACE

@@ -463,8 +463,22 @@ int wino_batched_gemm(const float *a, const float *b, float *out, int64_t T, int
     const double flops = 2.0 * kXi * (double)T * N * Kc;
     const double bytes = 4.0 * kXi * ((double)T * N + (double)T * Kc + (double)N * Kc);
     mrcnn::ProfScope prof(big ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_FWD_64, flops, bytes, s);
-    if (big) launch_kernel<2, 2, FWD>(p, tiles, 1, s, kXi);
-    else launch_kernel<1, 1, FWD>(p, tiles, 1, s, kXi);
+    const int rem = p.M % 128;
+    if (big && rem > 0 && rem <= 64 && p.M >= 256) {
+        // a last row tile that is at most half full (the RPN's 546 tiles of a 2 x 51 x 84 map:
+        // 4 x 128 + 34) runs as 64-row tiles instead of a whole 128-row tile of mostly padding
+        const int full = p.M - rem;
+        GemmParams q = p;
+        q.M = full;
+        launch_kernel<2, 2, FWD>(q, (int64_t)(full / 128) * mrcnn::ceil_div(p.N, 128), 1, s, kXi);
+        q.M = p.M;
+        q.m_lo = full;
+        launch_kernel<1, 1, FWD>(q, mrcnn::ceil_div(p.N, 64), 1, s, kXi);
+    } else if (big) {
+        launch_kernel<2, 2, FWD>(p, tiles, 1, s, kXi);
+    } else {
+        launch_kernel<1, 1, FWD>(p, tiles, 1, s, kXi);
+    }
     return mrcnn::check_launch("wino_batched_gemm");
 }
 

@@ -81,14 +81,29 @@ colsum_partial_kernel(const float *__restrict__ a, const float *__restrict__ b, 
         partial[(int64_t)split * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
-__global__ void colsum_final_kernel(const float *__restrict__ partial, int splits, int C,
-                                    float *__restrict__ out)
+// 64 columns x 4 lanes of splits per workgroup: lane group g sums the slabs s = g, g + 4, ... with
+// four loads in flight, then the four partial sums are combined in a fixed order (deterministic).
+// One thread per column walking all 128 slabs was a chain of 128 dependent L2 round trips: 30 us
+// on the critical path of every bias gradient.
+__global__ void __launch_bounds__(256)
+colsum_final_kernel(const float *__restrict__ partial, int splits, int C, float *__restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.f;
-    for (int s = 0; s < splits; ++s) acc += partial[(int64_t)s * C + c];
-    out[c] = acc;
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        int s = g;
+        for (; s + 12 < splits; s += 16) {
+            const float v0 = partial[(int64_t)s * C + c], v1 = partial[(int64_t)(s + 4) * C + c];
+            const float v2 = partial[(int64_t)(s + 8) * C + c], v3 = partial[(int64_t)(s + 12) * C + c];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; s < splits; s += 4) a0 += partial[(int64_t)s * C + c];
+    }
+    red[g][cx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && c < C) out[c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
 // ---- F.max_pooling_2d(x,3,2,1) cover_all, -inf padding ------------------------
@@ -266,7 +281,7 @@ static int colsum_impl(const float *a, const float *b, float *out, int64_t M, in
     if (splits < 1) splits = 1;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, s, a, b, M,
                        C, (float *)ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s,
                        (const float *)ws, splits, C, out);
     return mrcnn::check_launch("colsum");
 }
@@ -348,6 +363,53 @@ extern "C" int mrcnn_avgpool_bwd(const float *gy, float *gx, int R, int HW, int 
         hipLaunchKernelGGL(avgpool_bwd_kernel<false>, dim3(grid_for((int64_t)R * HW * C)), dim3(256),
                            0, s, gy, gx, R, HW, C, accumulate);
     return mrcnn::check_launch("avgpool_bwd");
+}
+
+namespace {
+__global__ void __launch_bounds__(256)
+head_tail_bwd_kernel(const float4 *__restrict__ g_pool, const float4 *__restrict__ g_rows,
+                     const int *__restrict__ slot, const float4 *__restrict__ y,
+                     float4 *__restrict__ g, int R, int HW, int cv)
+{
+    const int64_t total = (int64_t)R * HW * cv;
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        const int64_t rp = i / cv;
+        const int r = (int)(rp / HW), p = (int)(rp - (int64_t)r * HW);
+        float4 v = g_pool[(int64_t)r * cv + c];
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        const int sl = slot ? slot[r] : -1;
+        if (sl >= 0) {
+            const float4 a = g_rows[((int64_t)sl * HW + p) * cv + c];
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        const float4 m = y[i];
+        v.x = m.x > 0.f ? v.x : 0.f;
+        v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f;
+        v.w = m.w > 0.f ? v.w : 0.f;
+        g[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int mrcnn_head_tail_bwd(const float *g_pool, const float *g_rows, const int32_t *slot,
+                                   const float *y, float *g, int R, int HW, int C, void *stream)
+{
+    MRCNN_REQUIRE(R >= 0 && HW > 0 && C > 0 && C % 4 == 0, "head_tail_bwd: bad shape (C must be a multiple of 4)");
+    if (R == 0) return 0;
+    MRCNN_REQUIRE(g_pool && y && g, "head_tail_bwd: null pointer");
+    MRCNN_REQUIRE((g_rows == nullptr) == (slot == nullptr), "head_tail_bwd: g_rows and slot go together");
+    MRCNN_REQUIRE(aligned16(g_pool) && aligned16(y) && aligned16(g) && (!g_rows || aligned16(g_rows)),
+                  "head_tail_bwd: pointers must be 16-byte aligned");
+    const int64_t total = (int64_t)R * HW * (C / 4);
+    mrcnn::ProfScope prof(mrcnn::PROF_ELEMENTWISE, 0., 8.0 * (double)R * HW * C, mrcnn::as_stream(stream));
+    hipLaunchKernelGGL(head_tail_bwd_kernel, dim3(grid_for(total)), dim3(256), 0,
+                       mrcnn::as_stream(stream), (const float4 *)g_pool, (const float4 *)g_rows, slot,
+                       (const float4 *)y, (float4 *)g, R, HW, C / 4);
+    return mrcnn::check_launch("head_tail_bwd");
 }
 
 extern "C" int mrcnn_sgd_momentum_wd_ex(float *p, float *g, float *v, int64_t n, float lr,

@@ -688,12 +688,16 @@ _STAGE_RECORDS_GRAPH = True
 class _StageFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, strides, proj, poll, *params):
+    def forward(ctx, x, strides, proj, poll, tail_rows, *params):
         """``strides[i]`` / ``proj[i]``: conv1(/conv4) stride and has-projection flag of block
         i; ``poll``: optional callable invoked during backward at the stage's entry and after
         every block's weight gradients have been queued (parallel.DataParallelGradSync launches
-        the gradient buckets that are complete); ``params``: per block W1,s1,b1,W2,s2,b2,W3,s3,b3
-        (+ W4,s4,b4 when proj[i])."""
+        the gradient buckets that are complete); ``tail_rows``: None, or an int64 index tensor —
+        the node then returns ``(average_pooling(y) (N,C,1,1), y[tail_rows])`` instead of the
+        stage output y (the RoI head's two consumers of res5, models/mask_rcnn_resnet.py:186-195),
+        and its backward forms the gradient entering the last block from both in ONE pass,
+        ReLU mask included (``mrcnn_head_tail_bwd``); ``params``: per block
+        W1,s1,b1,W2,s2,b2,W3,s3,b3 (+ W4,s4,b4 when proj[i])."""
         _lib.require_device(x, params[0])
         x = nhwc(x)
         blocks, saved, pos, wino_v = [], [x], 0, []
@@ -710,7 +714,7 @@ class _StageFn(torch.autograd.Function):
             if uses_winograd(d2) and (WINOGRAD_TRAIN_FORWARD in (True, 'stage') or not training):
                 # (with a weight gradient to come, the transformed input is kept for it)
                 h2, v2 = wino_fwd(h1, nhwc(W2), d2, s2, b2, True,
-                                  keep_v=training and bool(ctx.needs_input_grad[4 + pos + 3]),
+                                  keep_v=training and bool(ctx.needs_input_grad[5 + pos + 3]),
                                   cache_for=None if training else W2,
                                   exact_signs=training and WINOGRAD_EXACT_SIGNS)
             else:
@@ -735,6 +739,18 @@ class _StageFn(torch.autograd.Function):
         ctx.wino_slots = [i for i, v in enumerate(wino_v) if v is not None]
         ctx.save_for_backward(*(saved + [wino_v[i] for i in ctx.wino_slots]))
         ctx.wT = None
+        ctx.tail = tail_rows is not None
+        if ctx.tail:
+            # the two consumers of the stage output, produced here so that backward receives
+            # their gradients separately (h itself is not an output of the node)
+            R_, C_ = h.shape[0], h.shape[1]
+            pooled = torch.empty((R_, C_), dtype=torch.float32, device=h.device)
+            _lib.call('mrcnn_avgpool_fwd', _lib.ptr(h), _lib.ptr(pooled), R_, h.shape[2] * h.shape[3],
+                      C_, _lib.stream_ptr())
+            sub = h.permute(0, 2, 3, 1).index_select(0, tail_rows).permute(0, 3, 1, 2)
+            slot = torch.full((R_,), -1, dtype=torch.int32, device=h.device)
+            slot[tail_rows] = torch.arange(tail_rows.numel(), dtype=torch.int32, device=h.device)
+            ctx.tail_slot = slot
         if PRETRANSPOSE_FILTERS and any(ctx.needs_input_grad):
             # The backward's forward-form dgrads need every filter flipped and transposed
             # (conv3 / conv4 with their affine scale folded in).  The weights are final for
@@ -749,10 +765,12 @@ class _StageFn(torch.autograd.Function):
                              for _, (_, _, _, W4), p0 in blocks], dev)
                 ctx.wT_ready = torch.cuda.Event()
                 ctx.wT_ready.record(side)
+        if ctx.tail:
+            return pooled.reshape(R_, C_, 1, 1), sub
         return h
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_rows=None):
         saved = list(ctx.saved_tensors)
         wino_v = dict(zip(ctx.wino_slots, saved[ctx.n_saved:]))
         saved = saved[:ctx.n_saved]
@@ -770,14 +788,16 @@ class _StageFn(torch.autograd.Function):
             acts.append((xin, h1, h2, y, s1, s2, s3, s4))
             xin = y
             pos += n
-        gy = nhwc(gy)
+        if not ctx.tail:
+            gy = nhwc(gy)
         # small-M layers (backbone stages) leave CUs idle: their weight gradients go to a
         # second stream so that they can share the GPU with the next dgrad
         d_top = ctx.blocks[-1][0][2]
-        side = wgrad_stream(gy.device) if (
+        dev_ = gy.device if gy is not None else g_rows.device
+        side = wgrad_stream(dev_) if (
             SMALL_WGRAD_SIDE_STREAM and d_top.N * d_top.P * d_top.Q <= SMALL_WGRAD_MAX_PIXELS) else None
         if ctx.wT is not None:
-            main = torch.cuda.current_stream(gy.device)
+            main = torch.cuda.current_stream(dev_)
             main.wait_event(ctx.wT_ready)
             for t in ctx.wT:
                 for buf in t.values():
@@ -785,14 +805,26 @@ class _StageFn(torch.autograd.Function):
             stage_wT = ctx.wT
         else:
             # all the stage's filter transposes in one launch
-            stage_wT = _stage_transposes(ctx.blocks, [(a[6], a[7]) for a in acts], gy.device)
+            stage_wT = _stage_transposes(ctx.blocks, [(a[6], a[7]) for a in acts], dev_)
         # gm: gradient w.r.t. the block output, already through that output's ReLU
-        gm = epilogue_bwd(gy, acts[-1][3], None)
+        if ctx.tail:
+            y_top = acts[-1][3]
+            R_, C_, Hh, Ww = y_top.shape
+            if gy is None:
+                gy = torch.zeros((R_, C_), dtype=torch.float32, device=dev_)
+            gp = gy.reshape(R_, C_).contiguous()
+            gr = nhwc(g_rows) if g_rows is not None else None
+            gm = empty_nhwc((R_, C_, Hh, Ww), dev_)
+            _lib.call('mrcnn_head_tail_bwd', _lib.ptr(gp), _lib.ptr(gr),
+                      _lib.ptr(ctx.tail_slot) if gr is not None else None, _lib.ptr(y_top),
+                      _lib.ptr(gm), R_, Hh * Ww, C_, _lib.stream_ptr())
+        else:
+            gm = epilogue_bwd(gy, acts[-1][3], None)
         for i in range(len(acts) - 1, -1, -1):
             x, h1, h2, y, s1, s2, s3, s4 = acts[i]
             (d1, d2, d3, d4), (W1, W2, W3, W4), p0 = ctx.blocks[i]
             wT = stage_wT[i]
-            base = 4 + p0                      # index of W1 among the forward inputs
+            base = 5 + p0                      # index of W1 among the forward inputs
             first = i == 0
             # what the gradient leaving this block must be masked with: the previous block's
             # output ReLU (= this block's input); the stage input belongs to someone else
@@ -842,8 +874,10 @@ class _StageFn(torch.autograd.Function):
         return tuple(grads)
 
 
-def building_block(x, blocks, first_stride=None, poll=None):
-    """A chain of Bottleneck links (chainer BuildingBlock) as one fused autograd node."""
+def building_block(x, blocks, first_stride=None, poll=None, tail_rows=None):
+    """A chain of Bottleneck links (chainer BuildingBlock) as one fused autograd node.  With
+    ``tail_rows`` (int64 row indices) it returns ``(average_pooling_2d(y, map size), y[tail_rows])``
+    instead of y — see _StageFn.forward."""
     strides, proj, params = [], [], []
     for i, b in enumerate(blocks):
         strides.append(b.conv1.stride if not (i == 0 and first_stride is not None) else first_stride)
@@ -855,6 +889,6 @@ def building_block(x, blocks, first_stride=None, poll=None):
     global _STAGE_RECORDS_GRAPH
     _STAGE_RECORDS_GRAPH = torch.is_grad_enabled()
     try:
-        return _StageFn.apply(x, tuple(strides), tuple(proj), poll, *params)
+        return _StageFn.apply(x, tuple(strides), tuple(proj), poll, tail_rows, *params)
     finally:
         _STAGE_RECORDS_GRAPH = True

@@ -68,6 +68,7 @@ class ResNetRoIHead(torch.nn.Module):
         self.roi_size = roi_size
         self.spatial_scale = spatial_scale
         self.pooling_func = pooling_func
+        self.fused_tail = True      # developer switch: res5's two consumers inside the stage node
 
     def forward(self, x, rois, roi_indices, pred_bbox=True, pred_mask=True, mask_rows=None):
         """Reference: models/mask_rcnn_resnet.py:168-196.
@@ -79,6 +80,11 @@ class ResNetRoIHead(torch.nn.Module):
         roi_indices = roi_indices.to(torch.float32)
         indices_and_rois = torch.cat((roi_indices[:, None], rois), dim=1)
         res5_stride = self.roi_size // 7
+        # Both consumers of res5 wanted and the mask branch on a row subset (training): the fused
+        # stage hands back (pool5, res5[mask_rows]) and combines their gradients in one pass
+        fused_tail = pred_bbox and pred_mask and mask_rows is not None and \
+            getattr(self.res5, 'fused_stage', False) and self.fused_tail
+        kw = dict(tail_rows=mask_rows) if fused_tail else {}
         if res5_stride > 1 and self.pooling_func is functions.roi_align_2d:
             # res5.a reads the pooled map only through 1x1 stride-s convolutions (conv1 and
             # the shortcut conv4), i.e. only the bins (s*i, s*j): pool just those and run the
@@ -86,19 +92,23 @@ class ResNetRoIHead(torch.nn.Module):
             pool = self.pooling_func(
                 x, indices_and_rois, outh=self.roi_size, outw=self.roi_size,
                 spatial_scale=self.spatial_scale, axes='yx', bin_stride=res5_stride)
-            res5 = self.res5(pool, first_stride=1)
+            res5 = self.res5(pool, first_stride=1, **kw)
         else:
             pool = self.pooling_func(
                 x, indices_and_rois, outh=self.roi_size, outw=self.roi_size,
                 spatial_scale=self.spatial_scale, axes='yx')
-            res5 = self.res5(pool)
+            res5 = self.res5(pool, **kw)
 
         roi_cls_locs = roi_scores = roi_masks = None
         res5_fg = None
-        if pred_bbox and pred_mask and mask_rows is not None:
+        pool5 = None
+        if fused_tail:
+            pool5, res5_fg = res5
+        elif pred_bbox and pred_mask and mask_rows is not None:
             res5, res5_fg = F.fanout_rows(res5, mask_rows)
         if pred_bbox:
-            pool5 = F.average_pooling_2d(res5, 7, stride=7)
+            if pool5 is None:
+                pool5 = F.average_pooling_2d(res5, 7, stride=7)
             fc = F.linear(pool5, self.cls_loc_score.W, self.cls_loc_score.b)
             roi_cls_locs = fc[:, :4 * self.n_class]
             roi_scores = fc[:, 4 * self.n_class:5 * self.n_class]

@@ -309,6 +309,15 @@ int mrcnn_maxpool3x3s2p1_fwd(const float *x, float *y, int N, int H, int W, int 
 int mrcnn_avgpool_fwd(const float *x, float *y, int R, int HW, int C, void *stream);
 int mrcnn_avgpool_bwd(const float *gy, float *gx, int R, int HW, int C,
                       int accumulate, void *stream);
+/* Gradient entering res5's last block from the two consumers of its output y (R,HW,C)
+ * (models/mask_rcnn_resnet.py:186-195: average pooling -> cls_loc / score, and deconv6 on the
+ * foreground rows), already through y's ReLU — one pass instead of avgpool backward + row
+ * scatter-add + ReLU mask (three passes over the 411 MB tensor):
+ *   g[r,p,c] = (g_pool[r,c] / HW + (slot[r] >= 0 ? g_rows[slot[r],p,c] : 0)) * (y[r,p,c] > 0)
+ * g_rows (F,HW,C) / slot (R) int32 may both be NULL (no row consumer).  Same operation order
+ * as the three separate kernels, so the result is bit-identical to them. */
+int mrcnn_head_tail_bwd(const float *g_pool, const float *g_rows, const int32_t *slot,
+                        const float *y, float *g, int R, int HW, int C, void *stream);
 
 /* ---- Losses (models/mask_rcnn_train_chain.py:163-181,192-213) -------------- */
 /* All loss kernels write loss[0] (device scalar, already normalised) and, when gx
