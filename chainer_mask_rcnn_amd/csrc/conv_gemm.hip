@@ -61,7 +61,7 @@ constexpr int BK = MRCNN_GEMM_BK;
 constexpr bool single_buffered(int tm, int mode, bool masked)
 {
     if (tm == 1) return MRCNN_GEMM_SINGLEBUF_SMALL != 0 && !masked && mode == 0;
-    return MRCNN_GEMM_SINGLEBUF != 0 && tm == 2 && !masked &&
+    return MRCNN_GEMM_SINGLEBUF != 0 && tm >= 2 && !masked &&
            (mode == 0 || (mode == 2 && MRCNN_GEMM_SINGLEBUF_WGRAD != 0));
 }
 // minimum workgroups per CU the register allocation must allow (256-thread workgroups: one
@@ -72,7 +72,7 @@ constexpr int min_blocks(int tm, int mode, bool masked)
 #ifdef MRCNN_GEMM_BIGBLOCKS     // experiment: resident workgroups per CU of the 128x128 kernels
     return tm == 2 ? MRCNN_GEMM_BIGBLOCKS : 6;
 #else
-    return tm == 2 ? 3 : 6;
+    return tm == 4 ? 2 : (tm == 2 ? 3 : 6);
 #endif
 }
 // Experiment, off by default: the last workgroup of a wgrad tile to arrive sums the split-K
@@ -256,6 +256,11 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
     return make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
 }
 
+// Round-3 tile-shape experiments, both bit-checked against this kernel and removed again
+// (profiles/r03_exp_tiles.txt): 256 x 128 workgroup tiles (a wave owns 128 x 64, 255 VGPRs, two
+// workgroups per CU) reach 85 vs 127 TFLOP/s on res5's 512 -> 2048 and 128 x 64 tiles (a wave
+// owns 64 x 32, four workgroups per CU) 116 vs 127: with fp32 MFMA the number of interleaved
+// waves per SIMD matters more than the bytes staged per MFMA, in both directions from 3.
 // (A "ping-pong" variant — 512-thread workgroups running two tiles in antiphase, one group
 // issuing MFMAs while the other stages — was measured slower, 110 vs 122 TFLOP/s on res5 3x3:
 // one wave per SIMD cannot keep the fp32 MFMA pipe as full as interleaved free-running waves.
@@ -817,7 +822,7 @@ conv_gemm_kernel(const GemmParams p)
 #endif
     constexpr int EG = 8;       // accumulator rows handled per batch of auxiliary loads
 
-    if constexpr (MODE == FWD && TM == 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
+    if constexpr (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
         // Forward-form launches: the accumulators (one column x 16 rows per lane) are turned
         // into row-major float4s through the wave's corner of the LDS stages, so the residual
         // / mask reads and the output stores are 16 B per lane — a quarter of the memory
@@ -827,7 +832,7 @@ conv_gemm_kernel(const GemmParams p)
         constexpr int LDW = CW + 4;                 // padded LDS row
         constexpr int F4 = CW / 4, RPI = 64 / F4;   // float4 per row, rows per pass of the wave
         constexpr int NK = 32 / RPI;                // passes per 32-row half
-        constexpr int QG = TM == 2 ? 4 : 2;         // passes whose loads are in flight together
+        constexpr int QG = TM >= 2 ? 4 : 2;         // passes whose loads are in flight together
         __syncthreads();                            // every wave is done with the K loop's LDS
 #ifdef MRCNN_GEMM_CLOCKPROBE
 #define PROBE2(k) if (tid == 0 && probe_slot < (unsigned)kProbeSlots) g_probe2[probe_slot * 8 + (k)] = __builtin_amdgcn_s_memrealtime();
@@ -1165,7 +1170,7 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
     GemmParams p = p0;
     {
         // resident workgroups per CU of this instantiation (registers / LDS, see min_blocks)
-        const int slots = single_buffered(TM, MODE, MASKED) ? (TM == 2 ? 3 : 6) : (TM == 2 ? 2 : 4);
+        const int slots = TM == 4 ? 2 : single_buffered(TM, MODE, MASKED) ? (TM == 2 ? 3 : 6) : (TM == 2 ? 2 : 4);
         const int64_t wgs = tiles * splits * batch;
         // K slices one workgroup walks and the matrix-pipe cycles of one of its waves per slice
         const int64_t slices = MODE == WGRAD ? mrcnn::ceil_div(p.split_len, BK)
@@ -1219,7 +1224,7 @@ void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
     // profiler buckets follow the kernel SYMBOL (what rocprofv3 reports): the forward-form
     // instantiation runs forward convolutions and the transposed-filter dgrads alike
     mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
-                              (TM == 2 ? 0 : 1),
+                              (TM >= 2 ? 0 : 1),
                           flops, bytes, s);
     launch_kernel<TM, TN, MODE>(p, blocks, splits, s);
 }
@@ -1344,7 +1349,7 @@ bool launch_fused_tail(GemmParams p, int rows_main, hipStream_t s)
         const double flops = 2.0 * p.M * p.N * kdepth;
         const double bytes = 4.0 * ((double)p.M * p.N + (double)p.M * p.Kc + (double)p.N * kdepth);
         mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
-                                  (TM == 2 ? 0 : 1),
+                                  (TM >= 2 ? 0 : 1),
                               flops, bytes, s);
         launch_kernel<TM, TN, MODE>(p, main_tiles + tail_tiles * splits, 1, s);
     }
