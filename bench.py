@@ -364,6 +364,11 @@ def main():
                          'examples/train_common.py:219-225); 0 = skip')
     ap.add_argument('--no-fg-capped', dest='fg_capped', action='store_false',
                     help='skip the second measurement with the proposal sampler at its foreground cap')
+    ap.add_argument('--no-prefetch-frozen', dest='prefetch_frozen', action='store_false',
+                    help="do not run the next batch's frozen prefix (conv1 .. res2) beside the backbone "
+                         'backward of the current step')
+    ap.add_argument('--no-winograd-forward', dest='winograd_forward', action='store_false',
+                    help="skip the measurement with res5's 3x3 forward on the Winograd route")
     ap.add_argument('--no-device-targets', dest='device_targets', action='store_false',
                     help='skip the measurement with the target creators on the device')
     ap.add_argument('--pipeline-examples', type=int, default=16,
@@ -428,6 +433,9 @@ def main():
                                             bucket_bytes=parallel_bucket_bytes,
                                             defer=args.defer_wgrad)
     imgs_d = torch.tensor(imgs, device=device).contiguous(memory_format=torch.channels_last)
+
+    if args.prefetch_frozen:
+        chain.next_imgs = imgs_d       # resident batch: the next iteration's images are known
 
     def step():
         return opt.update(chain, imgs_d, bboxes, labels, masks, scales)
@@ -501,6 +509,12 @@ def main():
             torch.cuda.current_stream(device).wait_event(ev)
             x.record_stream(torch.cuda.current_stream(device))
             stage(k + 1)
+            if args.prefetch_frozen:
+                def nxt(k1=k + 1):
+                    t, e = staged[k1]
+                    torch.cuda.current_stream(device).wait_event(e)     # the upload of batch k+1
+                    return t
+                chain.next_imgs = nxt
             b = host[k % K]
             return opt.update(chain, x, b[1], b[2], b[3], b[4])
 
@@ -512,6 +526,7 @@ def main():
             loss_r = rot_step(k)
         fence()
         el_r = max_over_ranks(time.perf_counter() - t0)
+        chain.next_imgs = imgs_d if args.prefetch_frozen else None
         rotating = dict(value=round(args.steps * args.batch * world / el_r, 3), unit='images/sec',
                         ms_per_step=round(el_r / args.steps * 1e3, 3), batches=K,
                         input='rotating+h2d: %d pre-generated pinned host batches, every step uploads '
@@ -569,6 +584,29 @@ def main():
                                     'draws stay on the host in the reference order (identical samples)',
                            loss=round(float(loss_d.item()), 5))
 
+    # ---- the same step with the RoI head's 3x3 FORWARD on the Winograd route too ----------------
+    wino_fwd = None
+    if args.winograd_forward:
+        from chainer_mask_rcnn_amd.functions import conv as conv_mod
+        prev_mode = conv_mod.WINOGRAD_TRAIN_FORWARD
+        conv_mod.WINOGRAD_TRAIN_FORWARD = 'stage'
+        for _ in range(max(2, args.warmup)):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_w = step()
+        fence()
+        el_w = max_over_ranks(time.perf_counter() - t0)
+        conv_mod.WINOGRAD_TRAIN_FORWARD = prev_mode
+        wino_fwd = dict(value=round(args.steps * args.batch * world / el_w, 3), unit='images/sec',
+                        ms_per_step=round(el_w / args.steps * 1e3, 3),
+                        workload="same step, functions.conv.WINOGRAD_TRAIN_FORWARD = 'stage': res5's three "
+                                 '3x3 forward convolutions on the F(4x4,3x3) route as well (the shipped '
+                                 'default keeps them on the direct kernel: DESIGN.md section 4.3, '
+                                 'profiles/r03_seed_study.json)',
+                        loss=round(float(loss_w.item()), 5))
+
     # ---- third measurement: the same step fed by the train loop's input pipeline ----------------
     pipeline = None
     if args.pipeline_examples > 0:
@@ -579,7 +617,7 @@ def main():
                                      height=int(round(args.height * 0.6)), width=int(round(args.width * 0.6)),
                                      virtual_len=8192)
         it = TL.SerialIterator(TL.TransformDataset(data, cmr.datasets.MaskRCNNTransform(model)), args.batch)
-        loop = TL.TrainLoop(it, chain, opt, device)
+        loop = TL.TrainLoop(it, chain, opt, device, prefetch_frozen=args.prefetch_frozen)
         for _ in range(max(2, args.warmup)):
             loop.step()
         fence()
@@ -590,6 +628,7 @@ def main():
         fence()
         el_p = max_over_ranks(time.perf_counter() - t0)
         loop.close()
+        chain.next_imgs = None
         pipeline = dict(value=round(args.steps * args.batch * world / el_p, 3), unit='images/sec',
                         ms_per_step=round(el_p / args.steps * 1e3, 3),
                         input='tools/train_loop.py: %d decoded uint8 HWC host examples (%dx%d, 8 '
@@ -630,6 +669,11 @@ def main():
                                            'per-frequency GEMMs)',
                             avg_launch_us=round(d['total_ms'] * 1e3 / d['launches'], 2),
                             launches_per_step=d['launches'] / args.steps,
+                            # HBM-bound kernels of the step: algorithmic bytes / HIP-event time vs 8 TB/s
+                            hbm_kernels={k: dict(gbs=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1),
+                                                 frac_of_hbm_peak=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                                 avg_launch_us=round(v['total_ms'] * 1e3 / v['launches'], 1))
+                                         for k, v in timed.items() if k.startswith('roi_align')},
                             kernels={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
                                              tflops=round(v['flops'] / (v['total_ms'] * 1e-3) / 1e12, 2)
                                              if v['flops'] else None,
@@ -682,6 +726,8 @@ def main():
             out['fg_capped'] = fg_capped
         if dev_targets is not None:
             out['device_targets'] = dev_targets
+        if wino_fwd is not None:
+            out['winograd_forward'] = wino_fwd
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         emit_json(out)

@@ -190,8 +190,13 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag='default'):
-    """Caller-owned scratch, cached per (device, tag); grows monotonically."""
-    key = (str(device), tag)
+    """Caller-owned scratch, cached per (device, current stream, tag); grows monotonically.
+    Scratch is stream-ordered: two streams that run the same op concurrently (the weight-gradient
+    side stream, the deferred-gradient stream, the input pipeline's stream, the frozen-prefix
+    prefetch) must never share a buffer, so the stream is part of the key."""
+    dev = torch.device(device)
+    sid = torch.cuda.current_stream(dev).cuda_stream if dev.type == 'cuda' else 0
+    key = (str(device), sid, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -40,9 +40,11 @@ hipEvent_t get_event()
 bool prof_timed(int kind)
 {
     if (g_prof_mode == 1) return true;
-    // mode 2: only the forward-form 128x128 GEMM — the dominant kernel symbol of both workloads
-    // (half of the GPU time, profiles/*_kernel_stats.csv)
-    return g_prof_mode == 2 && kind == PROF_CONV_FWD_128;
+    // mode 2: the forward-form 128x128 GEMM — the dominant kernel symbol of both workloads (half
+    // of the GPU time, profiles/*_kernel_stats.csv) — and the two ROIAlign launches of a step
+    // (HBM-bound kernels the north star asks a GB/s figure for; two event pairs per step)
+    return g_prof_mode == 2 && (kind == PROF_CONV_FWD_128 || kind == PROF_ROI_ALIGN_FWD ||
+                                kind == PROF_ROI_ALIGN_BWD);
 }
 bool prof_enabled(int) { return g_prof_mode != 0; }
 

@@ -88,6 +88,10 @@ class MaskRCNNTrainChain(torch.nn.Module):
         # creators already overlap with the GPU and the device path adds read-backs.
         self.device_targets = False
         self.host_timeline = None          # developer aid: list of (label, perf_counter) marks
+        # The image batch of the NEXT iteration (device tensor, or a callable returning it / None),
+        # when the caller already has it — a resident batch, the input pipeline's prefetched one.
+        # Its frozen prefix then runs beside this step's backbone backward.  None: off.
+        self.next_imgs = None
 
     def forward(self, imgs, bboxes, labels, masks, scales):
         """imgs (N,3,H,W) device tensor; bboxes / labels / masks: per-image sequences of
@@ -109,6 +113,16 @@ class MaskRCNNTrainChain(torch.nn.Module):
         if self.features_grad_hook is not None and features.requires_grad:
             # fires once the head's and the RPN's backward are both done
             features.register_hook(self.features_grad_hook)
+        nxt = self.next_imgs
+        if nxt is not None and features.requires_grad and hasattr(self.mask_rcnn.extractor, 'prefetch_frozen'):
+            # the NEXT batch's frozen prefix (conv1 .. res2) is queued on a side stream at the
+            # moment the backbone's backward begins (models/resnet_extractor.py:prefetch_frozen)
+            def _prefetch(g, nxt=nxt, ext=self.mask_rcnn.extractor):
+                t = nxt() if callable(nxt) else nxt
+                if t is not None:
+                    ext.prefetch_frozen(t)
+                return None
+            features.register_hook(_prefetch)
         # The deterministic half of the RPN target assignment needs only the ground truth:
         # start it on worker threads now (NumPy releases the GIL) so it overlaps with the
         # GPU's extractor/RPN/head work; its np.random draws happen later, in order.

@@ -133,6 +133,9 @@ def pack_stem_filter(W):
     return out
 
 
+_PREFETCH_STREAMS = {}
+
+
 class ResNetExtractorBase(torch.nn.Module):
 
     target_layer = 'res4'
@@ -151,6 +154,7 @@ class ResNetExtractorBase(torch.nn.Module):
         if not remove_layers or 'res5' not in remove_layers:
             self.res5 = BuildingBlock(n[3], 1024, 512, 2048, 2)
         self._stem_cache = None
+        self._prefetched = None       # (key, image batch, frozen-prefix activations, event)
         # optional {stage name: tensor hook}, fired when backward has passed the stage's output
         # (parallel.DataParallelGradSync polls its gradient buckets there)
         self.stage_hooks = {}
@@ -176,11 +180,69 @@ class ResNetExtractorBase(torch.nn.Module):
             ('res5', [self.res5]),
         ])
 
+    # -- frozen prefix one step ahead ----------------------------------------------------------
+    # conv1 .. freeze_at (res2) carry no gradient and their weights never change during training
+    # (models/resnet_extractor.py:86-87 + examples/train_common.py:185-190), so their forward for
+    # the NEXT image batch depends on nothing the current step produces.  `prefetch_frozen(x)`
+    # queues it on a side stream; MaskRCNNTrainChain calls it from the hook that fires when the
+    # head's and the RPN's backward are done — the batch-2 backbone backward that follows leaves
+    # CUs idle (small-M GEMMs), and these equally small launches fill them.  `forward(x)` on the
+    # SAME tensor then starts from the prefetched activations.  Values are those of an ordinary
+    # forward (same kernels, same inputs); anything that writes the frozen weights must call
+    # `drop_prefetched()` (the serializers do).
+    def _frozen_prefix(self, x):
+        h = x
+        with torch.no_grad():
+            for key, funcs in self.functions.items():
+                for func in funcs:
+                    h = func(h)
+                if key == self.freeze_at:
+                    break
+        return h.detach()
+
+    @staticmethod
+    def _prefetch_key(x):
+        return (id(x), x._version, x.data_ptr(), tuple(x.shape))
+
+    def prefetch_frozen(self, x):
+        if self.freeze_at is None or not isinstance(x, torch.Tensor) or not x.is_cuda:
+            return
+        if self._prefetched is not None and self._prefetched[0] == self._prefetch_key(x):
+            return
+        dev = x.device
+        key = str(dev)
+        if key not in _PREFETCH_STREAMS:
+            _PREFETCH_STREAMS[key] = torch.cuda.Stream(device=dev)
+        side, main = _PREFETCH_STREAMS[key], torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            h = self._frozen_prefix(x)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        x.record_stream(side)
+        self._prefetched = (self._prefetch_key(x), x, h, ready)
+
+    def drop_prefetched(self):
+        self._prefetched = None
+
     def forward(self, x):
         assert self.freeze_at is None or self.freeze_at in self.functions
         h = x
         frozen = self.freeze_at is not None
+        pre, self._prefetched = self._prefetched, None
+        skip_until = None
+        if pre is not None and isinstance(x, torch.Tensor) and pre[0] == self._prefetch_key(x) \
+                and torch.is_grad_enabled():
+            main = torch.cuda.current_stream(x.device)
+            main.wait_event(pre[3])
+            h = pre[2]
+            h.record_stream(main)
+            skip_until, frozen = self.freeze_at, False
         for key, funcs in self.functions.items():
+            if skip_until is not None:
+                if key == skip_until:
+                    skip_until = None
+                continue
             for func in funcs:
                 if frozen:
                     with torch.no_grad():

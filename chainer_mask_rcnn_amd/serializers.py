@@ -56,6 +56,9 @@ def load_npz(path, model, strict=True):
     fused = _fused_parts(model)
     used = set()
     conv.weights_changed()                 # cached transformed filters of inference calls
+    ext = getattr(model, 'extractor', None)
+    if ext is not None and hasattr(ext, 'drop_prefetched'):
+        ext.drop_prefetched()              # a frozen prefix computed with the old weights
     with torch.no_grad():
         for name, p in model.named_parameters():
             owner, leaf = name.rsplit('.', 1)

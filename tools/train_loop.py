@@ -121,8 +121,9 @@ def keep_host_buffers_mapped():
 class TrainLoop(object):
     """iterator -> converter -> optimizer.update, the input pipeline one batch ahead."""
 
-    def __init__(self, iterator, chain, optimizer, device, prefetch=True):
+    def __init__(self, iterator, chain, optimizer, device, prefetch=True, prefetch_frozen=True):
         self.iterator, self.chain, self.optimizer = iterator, chain, optimizer
+        self.prefetch_frozen = prefetch_frozen
         self.device = torch.device(device)
         self.converter = make_converter(self.device)
         self.prefetch = prefetch and self.device.type == 'cuda'
@@ -170,11 +171,24 @@ class TrainLoop(object):
             batch[0].record_stream(main)
         return batch
 
+    def _peek_next_images(self):
+        fut = self._pending
+        if fut is None or not fut.done():
+            return None
+        batch, ready = fut.result()
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
+        return batch[0]
+
     # -- updater ------------------------------------------------------------------------------
     def step(self):
         """One iteration of StandardUpdater.update_core: returns the loss (device tensor)."""
         batch = self._take()
         self._pending = self._submit()          # batch k+1 is prepared while step k runs
+        if self.prefetch_frozen and hasattr(self.chain, 'next_imgs'):
+            # the extractor's frozen prefix of batch k+1 runs beside step k's backbone backward,
+            # if the worker has delivered that batch by then (never waits for it)
+            self.chain.next_imgs = self._peek_next_images
         imgs, bboxes, labels, masks, scales = batch
         loss = self.optimizer.update(self.chain, imgs, bboxes, labels, masks, scales)
         self.iteration += 1
