@@ -748,8 +748,10 @@ class _StageFn(torch.autograd.Function):
             _lib.call('mrcnn_avgpool_fwd', _lib.ptr(h), _lib.ptr(pooled), R_, h.shape[2] * h.shape[3],
                       C_, _lib.stream_ptr())
             sub = h.permute(0, 2, 3, 1).index_select(0, tail_rows).permute(0, 3, 1, 2)
-            slot = torch.full((R_,), -1, dtype=torch.int32, device=h.device)
-            slot[tail_rows] = torch.arange(tail_rows.numel(), dtype=torch.int32, device=h.device)
+            slot = getattr(tail_rows, '_mrcnn_slot', None)     # built on the host by the caller
+            if slot is None:
+                slot = torch.full((R_,), -1, dtype=torch.int32, device=h.device)
+                slot[tail_rows] = torch.arange(tail_rows.numel(), dtype=torch.int32, device=h.device)
             ctx.tail_slot = slot
         if PRETRANSPOSE_FILTERS and any(ctx.needs_input_grad):
             # The backward's forward-form dgrads need every filter flipped and transposed

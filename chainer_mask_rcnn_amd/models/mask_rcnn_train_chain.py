@@ -227,9 +227,13 @@ class MaskRCNNTrainChain(torch.nn.Module):
         self._last_n_fg = int((gt_roi_labels_h > 0).sum())
         fg_rows = np.flatnonzero(gt_roi_labels_h > 0) if self.mask_branch_fg_only else np.zeros(0)
         cat = lambda parts: np.concatenate(parts, axis=0)
-        sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels, fg_rows_d = _upload_many(
-            [cat(sample_rois), cat(sample_roi_indices), cat(gt_roi_locs), gt_roi_labels_h, fg_rows],
-            [torch.float32, torch.int32, torch.float32, torch.int32, torch.int64], dev)
+        # row -> position among the foreground rows (-1: background), for the fused res5 tail
+        fg_slot = np.full((len(gt_roi_labels_h),), -1, np.int32)
+        fg_slot[fg_rows.astype(np.int64)] = np.arange(len(fg_rows), dtype=np.int32)
+        sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels, fg_rows_d, fg_slot_d = _upload_many(
+            [cat(sample_rois), cat(sample_roi_indices), cat(gt_roi_locs), gt_roi_labels_h, fg_rows, fg_slot],
+            [torch.float32, torch.int32, torch.float32, torch.int32, torch.int64, torch.int32], dev)
+        fg_rows_d._mrcnn_slot = fg_slot_d
 
         # The reference runs the mask branch on every sampled RoI (:147-148) although
         # background rows carry all-ignored (-1) mask targets and therefore contribute
