@@ -673,7 +673,7 @@ def bottleneck(x, conv1, bn1, conv2, bn2, conv3, bn3, conv4=None, bn4=None, stri
 # the next dgrad share the GPU (same-box A/B: 54.4 -> 54.0 ms per step).  For the large res5
 # launches the same trick measured no overlap (USE_WGRAD_STREAM above).
 SMALL_WGRAD_SIDE_STREAM = True
-SMALL_WGRAD_MAX_PIXELS = 40000
+SMALL_WGRAD_MAX_PIXELS = int(_os.environ.get('MRCNN_SIDE_WGRAD_MAX_PIXELS', 40000))
 # Build the transposed filters of a stage during its forward, on the side stream (see _StageFn).
 # Measured (same-box A/B): 53.2 vs 53.0 ms per step — the 42 five-microsecond transposes cost
 # as much next to the forward GEMMs as between the backward ones; off by default.

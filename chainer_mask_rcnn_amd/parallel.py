@@ -167,11 +167,15 @@ class RcclExchange(object):
 def default_exchange(group=None):
     """RCCL behind the C ABI on a ROCm device, torch.distributed (gloo) on CPU.
 
-    If creating the C-ABI communicator fails on ANY rank (agreed through the control plane, so
-    no rank is left waiting in a collective), every rank falls back to torch.distributed's own
-    RCCL binding — still RCCL over xGMI, loudly reported (stderr, ``describe()['fallback']``)."""
+    If creating the C-ABI communicator fails on ANY rank, every rank learns it through the control
+    plane (so no rank is left waiting in a collective) and every rank RAISES: the gradient exchange
+    of this build is `mrcnn_allreduce_*` and nothing else.  Setting
+    ``MRCNN_ALLOW_TORCH_RCCL_FALLBACK=1`` opts into torch.distributed's own RCCL binding instead
+    (still RCCL over xGMI; reported on stderr and in ``describe()['fallback']``) — a debugging aid,
+    never selected silently."""
     if not (torch.cuda.is_available() and group is None):
         return TorchDistExchange(group)
+    import os
     import sys
     ex, err = None, ''
     try:
@@ -185,10 +189,18 @@ def default_exchange(group=None):
         return ex
     if ex is not None:
         ex.close()
+    why = err or 'the C-ABI communicator failed on a peer rank'
+    if os.environ.get('MRCNN_ALLOW_TORCH_RCCL_FALLBACK') != '1':
+        from . import _lib
+        raise _lib.MrcnnHipError(
+            'mrcnn_allreduce_init failed on at least one rank (%s).  The data-parallel gradient '
+            'exchange runs through libmrcnn_hip.so only; set MRCNN_ALLOW_TORCH_RCCL_FALLBACK=1 to '
+            "use torch.distributed's RCCL binding instead." % why)
     sys.stderr.write('[chainer_mask_rcnn_amd.parallel] mrcnn_allreduce_init failed on at least one '
-                     'rank (%s); falling back to torch.distributed nccl (RCCL)\n' % (err or 'peer rank'))
+                     'rank (%s); MRCNN_ALLOW_TORCH_RCCL_FALLBACK=1: using torch.distributed nccl '
+                     '(RCCL)\n' % why)
     fb = TorchDistExchange(None)
-    fb.fallback = err or 'C-ABI communicator failed on a peer rank'
+    fb.fallback = why
     return fb
 
 
