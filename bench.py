@@ -367,8 +367,9 @@ def main():
     ap.add_argument('--no-prefetch-frozen', dest='prefetch_frozen', action='store_false',
                     help="do not run the next batch's frozen prefix (conv1 .. res2) beside the backbone "
                          'backward of the current step')
-    ap.add_argument('--no-winograd-forward', dest='winograd_forward', action='store_false',
-                    help="skip the measurement with res5's 3x3 forward on the Winograd route")
+    ap.add_argument('--no-direct-head-forward', '--no-winograd-forward', dest='direct_head_forward',
+                    action='store_false',
+                    help="skip the measurement with res5's 3x3 forward on the direct kernel")
     ap.add_argument('--no-device-targets', dest='device_targets', action='store_false',
                     help='skip the measurement with the target creators on the device')
     ap.add_argument('--pipeline-examples', type=int, default=16,
@@ -584,12 +585,12 @@ def main():
                                     'draws stay on the host in the reference order (identical samples)',
                            loss=round(float(loss_d.item()), 5))
 
-    # ---- the same step with the RoI head's 3x3 FORWARD on the Winograd route too ----------------
+    # ---- the same step with the RoI head's 3x3 FORWARD on the direct kernel (round-2 default) ----
     wino_fwd = None
-    if args.winograd_forward:
+    if args.direct_head_forward:
         from chainer_mask_rcnn_amd.functions import conv as conv_mod
         prev_mode = conv_mod.WINOGRAD_TRAIN_FORWARD
-        conv_mod.WINOGRAD_TRAIN_FORWARD = 'stage'
+        conv_mod.WINOGRAD_TRAIN_FORWARD = 'conv2d'
         for _ in range(max(2, args.warmup)):
             step()
         fence()
@@ -601,10 +602,9 @@ def main():
         conv_mod.WINOGRAD_TRAIN_FORWARD = prev_mode
         wino_fwd = dict(value=round(args.steps * args.batch * world / el_w, 3), unit='images/sec',
                         ms_per_step=round(el_w / args.steps * 1e3, 3),
-                        workload="same step, functions.conv.WINOGRAD_TRAIN_FORWARD = 'stage': res5's three "
-                                 '3x3 forward convolutions on the F(4x4,3x3) route as well (the shipped '
-                                 'default keeps them on the direct kernel: DESIGN.md section 4.3, '
-                                 'profiles/r03_seed_study.json)',
+                        workload="same step, functions.conv.WINOGRAD_TRAIN_FORWARD = 'conv2d': res5's three "
+                                 '3x3 forward convolutions on the direct implicit-GEMM kernel instead of the '
+                                 'F(4x4,3x3) route (the default up to round 2; DESIGN.md section 4.3)',
                         loss=round(float(loss_w.item()), 5))
 
     # ---- third measurement: the same step fed by the train loop's input pipeline ----------------
@@ -727,7 +727,7 @@ def main():
         if dev_targets is not None:
             out['device_targets'] = dev_targets
         if wino_fwd is not None:
-            out['winograd_forward'] = wino_fwd
+            out['direct_head_forward'] = wino_fwd
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         emit_json(out)

@@ -67,6 +67,12 @@ def epilogue_bwd(gy, y=None, scale=None):
 
 _CONV_RECORDS_GRAPH = True
 
+# Test hook: when set to a list, every ReLU output this module produces (fused conv epilogues, the
+# three activations of each bottleneck of a fused stage, the deconvolution) is appended as
+# (kind, tensor) in call order — tests/test_gpu_model.py reads the ReLU DECISIONS of the HIP path
+# from it.  None (default): nothing is recorded or kept alive.
+RELU_TAP = None
+
 
 class _Conv2dFn(torch.autograd.Function):
     """y = relu?( affine?( conv(x, W) + b? ) + residual? )"""
@@ -105,6 +111,8 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.W_param = W
         ctx.b_param = b
         ctx.save_for_backward(x, Wc, scale, y if relu else None)
+        if RELU_TAP is not None and relu:
+            RELU_TAP.append(('conv', y))
         return y
 
     @staticmethod
@@ -220,6 +228,8 @@ class _Deconv2x2Fn(torch.autograd.Function):
         ctx.relu = relu
         ctx.W_param, ctx.b_param = W, b
         ctx.save_for_backward(x, Wc, y if relu else None)
+        if RELU_TAP is not None and relu:
+            RELU_TAP.append(('deconv', y))
         return y
 
     @staticmethod
@@ -405,7 +415,7 @@ WINOGRAD_MIN_WORK = int(_os.environ.get('MRCNN_WINO_MIN_WORK', 1 << 27))        
 # convolution and the losses; it cannot help the ReLUs further down a fused stage.
 # Without a graph (inference) every routed layer's forward takes it: only the per-op tolerance
 # applies there and it holds with a 30x margin.
-WINOGRAD_TRAIN_FORWARD = 'conv2d'     # False / 'conv2d' / 'stage' / True (both)
+WINOGRAD_TRAIN_FORWARD = True         # False / 'conv2d' / 'stage' / True (both; default since round 3)
 WINOGRAD_EXACT_SIGNS = True          # recorded graphs: ReLU decisions recomputed directly near zero
 WINOGRAD_DGRAD = True        # developer switches (error attribution, A/B timing)
 WINOGRAD_WGRAD = True
@@ -728,6 +738,8 @@ class _StageFn(torch.autograd.Function):
             d3 = make_desc(h2.shape, W3.shape, 1, 0)
             y = _fwd_raw(h2, nhwc(W3), d3, s3, b3, shortcut, True)
             blocks.append(((d1, d2, d3, d4), (W1, W2, W3, W4), pos))
+            if RELU_TAP is not None:
+                RELU_TAP.append(('block', (h1, h2, y)))
             saved += [h1, h2, y, s1, s2, s3] + ([s4] if pj else [])
             wino_v.append(v2)
             pos += n

@@ -47,22 +47,43 @@ def _affine(x, P, pre):
     return x * P[pre + '.W'].detach().view(1, -1, 1, 1) + P[pre + '.b'].detach().view(1, -1, 1, 1)
 
 
-def bottleneck(x, P, pre, stride, proj):
-    h = F.relu(_affine(F.conv2d(x, P[pre + '.conv1.W'], stride=stride), P, pre + '.bn1'))
-    h = F.relu(_affine(F.conv2d(h, P[pre + '.conv2.W'], padding=1), P, pre + '.bn2'))
+class Relus(object):
+    """ReLU bookkeeping of the reference graph.  ``masks`` {name: bool tensor}: use these
+    decisions instead of the graph's own (y = x * mask); ``pre``: filled with every ReLU's float64
+    pre-activation (detached) when it is a dict.  Names: '<bottleneck>.h1' / '.h2' / '.y',
+    'rpn.conv1', 'head.deconv6'."""
+
+    def __init__(self, masks=None, record=False):
+        self.masks = masks
+        self.pre = {} if record else None
+
+    def __call__(self, x, name):
+        if self.pre is not None:
+            self.pre[name] = x.detach()
+        if self.masks is not None and name in self.masks:
+            return x * self.masks[name].to(x.dtype)
+        return F.relu(x)
+
+
+_PLAIN = Relus()
+
+
+def bottleneck(x, P, pre, stride, proj, relus=_PLAIN):
+    h = relus(_affine(F.conv2d(x, P[pre + '.conv1.W'], stride=stride), P, pre + '.bn1'), pre + '.h1')
+    h = relus(_affine(F.conv2d(h, P[pre + '.conv2.W'], padding=1), P, pre + '.bn2'), pre + '.h2')
     h = _affine(F.conv2d(h, P[pre + '.conv3.W']), P, pre + '.bn3')
     sc = _affine(F.conv2d(x, P[pre + '.conv4.W'], stride=stride), P, pre + '.bn4') if proj else x
-    return F.relu(h + sc)
+    return relus(h + sc, pre + '.y')
 
 
-def building_block(x, P, pre, n, stride):
-    x = bottleneck(x, P, pre + '.a', stride, True)
+def building_block(x, P, pre, n, stride, relus=_PLAIN):
+    x = bottleneck(x, P, pre + '.a', stride, True, relus)
     for i in range(1, n):
-        x = bottleneck(x, P, pre + '.b%d' % i, 1, False)
+        x = bottleneck(x, P, pre + '.b%d' % i, 1, False, relus)
     return x
 
 
-def extractor(x, P, pre='extractor', blocks=(3, 4, 6)):
+def extractor(x, P, pre='extractor', blocks=(3, 4, 6), relus=_PLAIN):
     x = x.to(P.dtype)
     with torch.no_grad():
         h = F.conv2d(x, P[pre + '.conv1.W'], P[pre + '.conv1.b'], stride=2, padding=3)
@@ -70,13 +91,13 @@ def extractor(x, P, pre='extractor', blocks=(3, 4, 6)):
         h = F.max_pool2d(h, 3, 2, 1, ceil_mode=True)
         h = building_block(h, P, pre + '.res2', blocks[0], 1)
     h = h.detach()
-    h = building_block(h, P, pre + '.res3', blocks[1], 2)
-    h = building_block(h, P, pre + '.res4', blocks[2], 2)
+    h = building_block(h, P, pre + '.res3', blocks[1], 2, relus)
+    h = building_block(h, P, pre + '.res4', blocks[2], 2, relus)
     return h
 
 
-def rpn(feat, P, A, pre='rpn'):
-    h = F.relu(F.conv2d(feat, P[pre + '.conv1.W'], P[pre + '.conv1.b'], padding=1))
+def rpn(feat, P, A, pre='rpn', relus=_PLAIN):
+    h = relus(F.conv2d(feat, P[pre + '.conv1.W'], P[pre + '.conv1.b'], padding=1), pre + '.conv1')
     out = F.conv2d(h, P[pre + '.loc_score.W'], P[pre + '.loc_score.b'])
     n = feat.shape[0]
     nhwc = out.permute(0, 2, 3, 1)
@@ -85,14 +106,15 @@ def rpn(feat, P, A, pre='rpn'):
     return locs, scores
 
 
-def head(feat, rois_yx, roi_indices, P, n_class, roi_size, pre='head'):
+def head(feat, rois_yx, roi_indices, P, n_class, roi_size, pre='head', relus=_PLAIN):
     rois = torch.cat([roi_indices.float()[:, None], rois_yx.float()], 1)[:, [0, 2, 1, 4, 3]].contiguous()
     pool = _RefROIAlign.apply(feat, rois, roi_size, roi_size, 1. / 16)
-    res5 = building_block(pool, P, pre + '.res5', 3, roi_size // 7)
+    res5 = building_block(pool, P, pre + '.res5', 3, roi_size // 7, relus)
     pool5 = F.avg_pool2d(res5, 7, 7).flatten(1)
     fc = F.linear(pool5, P[pre + '.cls_loc_score.W'], P[pre + '.cls_loc_score.b'])
     cls_locs, scores = fc[:, :4 * n_class], fc[:, 4 * n_class:5 * n_class]
-    d = F.relu(F.conv_transpose2d(res5, P[pre + '.deconv6.W'], P[pre + '.deconv6.b'], stride=2))
+    d = relus(F.conv_transpose2d(res5, P[pre + '.deconv6.W'], P[pre + '.deconv6.b'], stride=2),
+              pre + '.deconv6')
     masks = F.conv2d(d, P[pre + '.mask.W'], P[pre + '.mask.b'])
     return cls_locs, scores, masks
 

@@ -101,7 +101,13 @@ def test_extractor_and_rpn_forward(dev, setup):
         assert got.shape == ref_roi.shape and np.array_equal(got, ref_roi)
 
 
-def test_train_step_matches_reference(dev, setup):
+def test_train_step_matches_reference(dev, setup, monkeypatch):
+    """The round-1/2 entrywise criterion, kept on the route it was written for (the direct head
+    forward): it is decided by which units sit within rounding of zero (profiles/r03_seed_study.json)
+    and therefore says little about any fp32 implementation; the well-posed statement for BOTH
+    routes is test_train_step_gradients_given_the_relu_decisions below."""
+    from chainer_mask_rcnn_amd.functions import conv as C
+    monkeypatch.setattr(C, 'WINOGRAD_TRAIN_FORWARD', 'conv2d')
     model, chain, imgs, bboxes, labels, masks = setup
     for p in chain.parameters():
         p.grad = None
@@ -170,10 +176,120 @@ def test_train_step_matches_reference(dev, setup):
     assert worst < 2e-3, (worst_name, worst)
 
 
+def _reference_step(model, chain, dev, imgs, bboxes, labels, masks, blocks, relus):
+    """Float64 CPU graph of one train step on the SAME sampled RoIs / targets as the HIP step
+    (the samplers' RNG stream is replayed); returns (losses, RefParams with .grad filled)."""
+    P = ref_model.RefParams(model)
+    feat = ref_model.extractor(torch.tensor(imgs), P, blocks=blocks, relus=relus)
+    rl, rs = ref_model.rpn(feat, P, 15, relus=relus)
+    with torch.no_grad():
+        locs, scores, rois, roi_indices, anchor = model.rpn(
+            model.extractor(torch.tensor(imgs, device=dev)), (H, W), [1., 1.])
+    np.random.seed(123)
+    ptc, atc = chain.proposal_target_creator, chain.anchor_target_creator
+    rois_h, idx_h = rois.cpu().numpy(), roi_indices.cpu().numpy()
+    parts = [ptc(rois_h[idx_h == i], bboxes[i], labels[i], masks[i]) for i in range(2)]
+    r_locs, r_labels = zip(*[atc(b, anchor.cpu().numpy(), (H, W)) for b in bboxes])
+    cat = lambda xs, dt: torch.tensor(np.concatenate(xs, 0), dtype=dt)
+    s_idx = [np.full(len(p[0]), i, np.int32) for i, p in enumerate(parts)]
+    cls_locs, sc, mk = ref_model.head(feat, cat([p[0] for p in parts], torch.float32),
+                                      cat(s_idx, torch.int32), P, 81, 14, relus=relus)
+    losses = ref_model.losses(rl, rs, cat(r_locs, torch.float32), cat(r_labels, torch.int32),
+                              cls_locs, sc, mk, cat([p[1] for p in parts], torch.float32),
+                              cat([p[2] for p in parts], torch.int32),
+                              cat([p[3] for p in parts], torch.int32))
+    sum(losses).backward()
+    return losses, P
+
+
+@pytest.mark.parametrize('route', ['conv2d', True])
+def test_train_step_gradients_given_the_relu_decisions(dev, setup, monkeypatch, route):
+    """Whole-graph parity in a form that is well-posed at the fp32 floor (DESIGN.md section 4.3,
+    profiles/r03_seed_study.json: the entrywise criterion of test_train_step_matches_reference is
+    decided by which units happen to sit within rounding of zero, for every fp32 implementation).
+    Two statements, for the direct head forward (WINOGRAD_TRAIN_FORWARD = 'conv2d': only the RPN's
+    conv1 routed) and the shipped default (True: res5's 3x3 forward on the Winograd route as well):
+
+    (1) DECISIONS.  Every ReLU decision of the HIP step (res3, res4, RPN conv1, res5, deconv6)
+        that differs from the float64 graph's belongs to a unit whose float64 pre-activation lies
+        within 1e-4 of the tensor's scale of zero (the north star's tolerance for a computed fp32
+        value, here including what the layers upstream contributed), and fewer than 1 in 100 000
+        units differ (measured: 2-10 of 4e7 direct, 58-67 routed).
+    (2) ARITHMETIC.  Given the SAME decisions (the float64 graph evaluated with the HIP step's
+        ReLU masks), every entry of every parameter gradient is within 1e-4 of the tensor's scale
+        of float64 — no percentile, no exemptions — and the six losses within 1e-4."""
+    from chainer_mask_rcnn_amd.functions import conv as C
+    model, chain, imgs, bboxes, labels, masks = setup
+    blocks = _BLOCKS[len(model.extractor.res4._names) == 23 and 101 or 50]
+    monkeypatch.setattr(C, 'WINOGRAD_TRAIN_FORWARD', route)
+    monkeypatch.setattr(chain, 'mask_branch_fg_only', False)      # deconv6's ReLU on every row
+    tap = []
+    monkeypatch.setattr(C, 'RELU_TAP', tap)
+    for p in chain.parameters():
+        p.grad = None
+    np.random.seed(123)
+    loss = chain(torch.tensor(imgs, device=dev), bboxes, labels, masks, [1., 1.])
+    monkeypatch.setattr(C, 'RELU_TAP', None)
+    loss.backward()
+    torch.cuda.synchronize()
+    rep = {k: float(v) for k, v in chain.report.items()}
+    # the taps in call order: res2 (frozen), res3, res4 blocks; RPN conv1; res5 blocks; deconv6
+    names = []
+    for stage, n in zip(('extractor.res2', 'extractor.res3', 'extractor.res4'), blocks):
+        names += ['%s.%s' % (stage, 'a' if i == 0 else 'b%d' % i) for i in range(n)]
+    names += ['rpn.conv1'] + ['head.res5.%s' % b for b in ('a', 'b1', 'b2')] + ['head.deconv6']
+    assert len(tap) == len(names), (len(tap), len(names))
+    hip_masks = {}
+    for name, (kind, t) in zip(names, tap):
+        if kind == 'block':
+            for sub, a in zip(('h1', 'h2', 'y'), t):
+                hip_masks['%s.%s' % (name, sub)] = (a > 0).cpu()
+        else:
+            hip_masks[name] = (t > 0).cpu()
+    del tap[:]
+    hip_masks = {k: v for k, v in hip_masks.items() if not k.startswith('extractor.res2')}
+
+    # (1) decisions against the float64 graph's own
+    rec = ref_model.Relus(record=True)
+    _reference_step(model, chain, dev, imgs, bboxes, labels, masks, blocks, rec)
+    n_units = n_diff = 0
+    worst = 0.
+    for name, m in hip_masks.items():
+        pre = rec.pre[name]
+        assert tuple(pre.shape) == tuple(m.shape), (name, pre.shape, m.shape)
+        diff = m != (pre > 0)
+        n_units += m.numel()
+        n_diff += int(diff.sum())
+        if diff.any():
+            w = float(pre[diff].abs().max() / pre.abs().max())
+            worst = max(worst, w)
+            assert w <= 1e-4, (name, w)
+    print('%s: %d of %d ReLU decisions differ from float64 (%.1e), all within %.1e of the scale of zero'
+          % (route, n_diff, n_units, n_diff / n_units, worst))
+    assert n_diff <= 1e-5 * n_units
+
+    # (2) arithmetic, given the decisions
+    parts, P = _reference_step(model, chain, dev, imgs, bboxes, labels, masks, blocks,
+                               ref_model.Relus(masks=hip_masks))
+    for n, v in zip(['rpn_loc_loss', 'rpn_cls_loss', 'roi_loc_loss', 'roi_cls_loss', 'roi_mask_loss'], parts):
+        assert abs(rep[n] - v.item()) <= 1e-4 * max(abs(v.item()), 1e-3), (n, rep[n], v.item())
+    worst, worst_name = 0., None
+    for name, p in model.named_parameters():
+        if name.startswith('extractor.conv1') or name.startswith('extractor.bn1') \
+                or name.startswith('extractor.res2') or '.bn' in name:
+            continue
+        ref = P[name].grad.detach().double()
+        err = float(((p.grad.detach().cpu().double() - ref).abs() / ref.abs().max().clamp_min(1e-12)).max())
+        if err > worst:
+            worst, worst_name = err, name
+    print('%s: worst gradient entry %.2e of the tensor scale (%s), given the decisions' % (route, worst, worst_name))
+    assert worst <= 1e-4, (worst_name, worst)
+
+
 def test_train_step_with_the_head_forward_on_the_winograd_route(dev, setup, monkeypatch):
-    """functions.conv.WINOGRAD_TRAIN_FORWARD = 'stage' (opt-in; bench.py reports it as
-    `winograd_forward`): res5's 3x3 forward convolutions on the F(4x4,3x3) route inside a recorded
-    graph.  Its outputs differ from the direct kernel's by ~1e-6 of the tensor scale, which flips
+    """functions.conv.WINOGRAD_TRAIN_FORWARD = True (the default; bench.py reports the step
+    with 'conv2d' as `direct_head_forward`): res5's 3x3 forward convolutions on the F(4x4,3x3)
+    route inside a recorded graph.  Its outputs differ from the direct kernel's by ~1e-6 of the tensor scale, which flips
     ten times as many ReLU decisions of units sitting at zero; each flip moves one row of a few
     weight gradients (profiles/r03_seed_study.json: over ten random instances the entrywise
     criterion of test_train_step_matches_reference passes / fails on the SAME instances with and
@@ -183,7 +299,7 @@ def test_train_step_with_the_head_forward_on_the_winograd_route(dev, setup, monk
     from chainer_mask_rcnn_amd.functions import conv as C
     model, chain, imgs, bboxes, labels, masks = setup
     runs = {}
-    for mode in ('conv2d', 'stage'):
+    for mode in ('conv2d', True):
         monkeypatch.setattr(C, 'WINOGRAD_TRAIN_FORWARD', mode)
         for p in chain.parameters():
             p.grad = None
@@ -195,10 +311,10 @@ def test_train_step_with_the_head_forward_on_the_winograd_route(dev, setup, monk
                       {n: p.grad.detach().double().cpu() for n, p in model.named_parameters()
                        if p.grad is not None})
     for k, v in runs['conv2d'][0].items():
-        assert abs(runs['stage'][0][k] - v) <= 1e-4 * max(abs(v), 1e-3), (k, runs['stage'][0][k], v)
+        assert abs(runs[True][0][k] - v) <= 1e-4 * max(abs(v), 1e-3), (k, runs[True][0][k], v)
     worst_l2, worst_max, worst_name = 0., 0., None
     for n, g0 in runs['conv2d'][1].items():
-        g1 = runs['stage'][1][n]
+        g1 = runs[True][1][n]
         l2 = float((g1 - g0).norm() / g0.norm().clamp_min(1e-30))
         mx = float((g1 - g0).abs().max() / g0.abs().max().clamp_min(1e-30))
         if l2 > worst_l2:

@@ -124,6 +124,7 @@ def test_stage_with_winograd_matches_direct(dev):
     gy = None
     res = {}
     saved = (C.WINOGRAD_MIN_CHANNELS, C.WINOGRAD_MIN_WORK)
+    saved_route = (C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD)
     C.WINOGRAD_MIN_CHANNELS, C.WINOGRAD_MIN_WORK = 1, 0      # route this narrow stage too
     for use in (False, True):
         C.USE_WINOGRAD = C.WINOGRAD_TRAIN_FORWARD = use
@@ -138,7 +139,7 @@ def test_stage_with_winograd_matches_direct(dev):
             res[use] = [y.detach().cpu().numpy(), xi.grad.cpu().numpy()] + \
                 [p.grad.cpu().numpy() for _, p in stage.named_parameters() if p.grad is not None]
         finally:
-            C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD = True, False
+            C.USE_WINOGRAD, C.WINOGRAD_TRAIN_FORWARD = saved_route
     C.WINOGRAD_MIN_CHANNELS, C.WINOGRAD_MIN_WORK = saved
     assert len(res[True]) == len(res[False]) > 4
     for a, b in zip(res[True], res[False]):
