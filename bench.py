@@ -490,7 +490,8 @@ def main():
             host.append(synthetic_batch(rng, args.batch, args.height, args.width))
         pinned = [torch.from_numpy(np.ascontiguousarray(h[0])).pin_memory() for h in host]
 
-        copy_stream = torch.cuda.Stream(device=device)
+        from chainer_mask_rcnn_amd.models.mask_rcnn_train_chain import copy_stream as _copy_stream
+        copy_stream = _copy_stream(device)
         staged = {}
 
         def stage(k):

@@ -19,6 +19,17 @@ _POOL = None
 _COPY_STREAMS = {}
 
 
+def copy_stream(dev):
+    """The host-to-device copy stream of ``dev`` (one per device for the whole process: input
+    pipelines should upload on it rather than create their own — the step uses four HIP streams
+    (compute, copy, weight gradients, deferred work) and a GPU has four hardware queues by default;
+    a fifth stream shares a queue with one of them and serialises work that was meant to overlap)."""
+    key = str(dev)
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _COPY_STREAMS[key]
+
+
 def _upload(array, dtype, dev):
     """Host array -> device tensor through a side stream.  A pageable host-to-device copy
     issued on the compute stream blocks the host until everything queued there (e.g. the whole
@@ -26,10 +37,7 @@ def _upload(array, dtype, dev):
     keeps preparing targets while the GPU computes.  The compute stream is ordered after it."""
     if dev.type != 'cuda':
         return torch.tensor(array, dtype=dtype, device=dev)
-    key = str(dev)
-    if key not in _COPY_STREAMS:
-        _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
-    side = _COPY_STREAMS[key]
+    side = copy_stream(dev)
     main = torch.cuda.current_stream(dev)
     with torch.cuda.stream(side):
         t = torch.tensor(array, dtype=dtype, device=dev)

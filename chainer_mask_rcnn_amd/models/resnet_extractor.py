@@ -133,9 +133,6 @@ def pack_stem_filter(W):
     return out
 
 
-_PREFETCH_STREAMS = {}
-
-
 class ResNetExtractorBase(torch.nn.Module):
 
     target_layer = 'res4'
@@ -210,10 +207,12 @@ class ResNetExtractorBase(torch.nn.Module):
         if self._prefetched is not None and self._prefetched[0] == self._prefetch_key(x):
             return
         dev = x.device
-        key = str(dev)
-        if key not in _PREFETCH_STREAMS:
-            _PREFETCH_STREAMS[key] = torch.cuda.Stream(device=dev)
-        side, main = _PREFETCH_STREAMS[key], torch.cuda.current_stream(dev)
+        # the stream the deferred weight gradients use (idle between two proposal windows), NOT a
+        # stream of its own: a fifth stream changes which HIP streams share a hardware queue
+        # (GPU_MAX_HW_QUEUES = 4) and the proposal chain then queues behind the deferred weight
+        # gradients — measured +2.4 ms under data parallelism, +6 ms with 5..8 queues
+        from ..functions.conv import defer_stream
+        side, main = defer_stream(dev), torch.cuda.current_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             h = self._frozen_prefix(x)

@@ -23,6 +23,8 @@ def main():
             k, v = kv.split('=')
             _lib.check(_lib.load().mrcnn_set_tuning(k.encode(), int(v)), 'set_tuning')
     imgs_d = torch.tensor(imgs, device=dev).contiguous(memory_format=torch.channels_last)
+    if int(os.environ.get('PREFETCH', 1)):
+        chain.next_imgs = imgs_d
     marks = []
 
     def mark(label):

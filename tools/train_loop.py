@@ -132,7 +132,8 @@ class TrainLoop(object):
         keep_host_buffers_mapped()
         self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='mrcnn-input') \
             if self.prefetch else None
-        self._stream = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        from chainer_mask_rcnn_amd.models.mask_rcnn_train_chain import copy_stream
+        self._stream = copy_stream(self.device) if self.prefetch else None
         self._pending = None
 
     # -- input pipeline -----------------------------------------------------------------------
