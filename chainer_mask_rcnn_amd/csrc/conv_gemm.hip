@@ -256,6 +256,27 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
     return make_float4(v.x * s.x, v.y * s.y, v.z * s.z, v.w * s.w);
 }
 
+// fp32 pair -> three packed bf16 pairs (low half = a, high half = b) with a = hi + mid + lo
+// exactly: each conversion rounds to nearest, each residual is exact in fp32.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = pack_bf16(a, b);
+    a -= __uint_as_float(h << 16);
+    b -= __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16(a, b);
+    a -= __uint_as_float(m << 16);
+    b -= __uint_as_float(m & 0xffff0000u);
+    l = pack_bf16(a, b);
+}
+
 // Round-3 tile-shape experiments, both bit-checked against this kernel and removed again
 // (profiles/r03_exp_tiles.txt): 256 x 128 workgroup tiles (a wave owns 128 x 64, 255 VGPRs, two
 // workgroups per CU) reach 85 vs 127 TFLOP/s on res5's 512 -> 2048 and 128 x 64 tiles (a wave
@@ -267,20 +288,38 @@ __device__ __forceinline__ float4 mul4(float4 v, float4 s)
 // Removed; see the history of this file.)
 // WPERM: WGRAD with position-major pixel order (GemmParams::perm_n) — a separate instantiation
 // because the natural-order kernel sits exactly at its 168-register budget.
-template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false>
-__global__ void __launch_bounds__(256, min_blocks(TM, MODE, MASKED))
+// SPLIT (opt-in, mrcnn_set_tuning("split_bf16", 1); forward-form 128x128 launches only): the
+// operands are staged as THREE bf16 planes each — a = a_hi + a_mid + a_lo EXACTLY (8 + 8 + 8
+// significand bits) — and a K step runs six v_mfma_f32_32x32x16_bf16 (hi*hi, hi*mid, mid*hi,
+// mid*mid, hi*lo, lo*hi; every product of two bf16 values is exact in fp32, accumulation is fp32).
+// The three dropped cross terms are <= 2^-24 of |a*b| each, i.e. of the order of the rounding
+// error of one fp32 multiply-add, so results stay fp32-accurate (tests/test_gpu_split_bf16.py
+// measures the error against float64 next to the fp32 MFMA kernel's), while the matrix pipe
+// does 6 x 32 instead of 8 x 64 cycles per 32x32x16 block.
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false>
+__global__ void __launch_bounds__(256, SPLIT ? 2 : min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
-    constexpr bool SINGLEBUF = single_buffered(TM, MODE, MASKED);
+    static_assert(!SPLIT || ((MODE == FWD || (MODE == WGRAD && !WPERM)) && TM == 2 && TN == 2 && BK == 32),
+                  "SPLIT: 128x128 forward form / weight gradient only");
+    constexpr bool SINGLEBUF = SPLIT || single_buffered(TM, MODE, MASKED);
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
     constexpr int AV = C_::A_V4, BV = C_::B_V4;
     constexpr bool HAS_MASK = MASKED;
     constexpr bool FWDLIKE = is_fwd(MODE);
-    __shared__ __attribute__((aligned(16))) float smem_all[1][SINGLEBUF ? 1 : 2][C_::A_FLOATS + C_::B_FLOATS];
+    // SPLIT stage: 3 planes per operand of [row][32 bf16 + 8 pad] (80-byte rows: conflict-free b128)
+    constexpr int SROW = BK + 8;                          // ushorts per plane row
+    constexpr int PLA = BM * SROW, PLB = BN * SROW;       // ushorts per plane
+    constexpr int STAGE_FLOATS = SPLIT ? 3 * (PLA + PLB) / 2 : C_::A_FLOATS + C_::B_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem_all[1][SINGLEBUF ? 1 : 2][STAGE_FLOATS];
 
-    float (*smem)[C_::A_FLOATS + C_::B_FLOATS] = smem_all[0];
+    float (*smem)[STAGE_FLOATS] = smem_all[0];
+    // SPLIT WGRAD: the 8-byte chunk index inside a plane row is XORed with an EVEN number that
+    // depends on the row's group of 16 (16-byte pairs stay together for the b128 fragment reads);
+    // the transposing writes of one instruction hit rows 4 apart, which would otherwise share banks
+    auto swz = [](int row) { return (SPLIT && MODE == WGRAD) ? ((row >> 4) & 3) << 1 : 0; };
     const int tid = threadIdx.x;
 #ifdef MRCNN_GEMM_CLOCKPROBE
     const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime();
@@ -380,6 +419,11 @@ conv_gemm_kernel(const GemmParams p)
     constexpr int A_RPP = 256 / A_TPR, B_RPP = 256 / B_TPR;  // k rows per pass
     const int wa_k = tid / A_TPR, wa_c4 = tid % A_TPR;
     const int wb_k = tid / B_TPR, wb_c4 = tid % B_TPR;
+    // k row (pixel of the slice) of a thread's i-th load of a K-strided tile.  SPLIT: AV
+    // CONSECUTIVE pixels per thread, so that the 4 channels x AV pixels it holds go to LDS as
+    // [channel][pixel] rows (the layout the bf16 MFMA fragments are read from) with 8-byte writes.
+    auto a_krow = [&](int i) { return SPLIT ? wa_k * AV + i : wa_k + A_RPP * i; };
+    auto b_krow = [&](int i) { return SPLIT ? wb_k * BV + i : wb_k + B_RPP * i; };
     int wr = 0, ws_ = 0, wc = 0;
     int wy_lo = 0, wx_lo = 0, wnvx = 1;   // WGRAD position-major: valid-position rectangle
     int wr_u = 0, ws_u = 0, wnv = 1;      // ... the tile's tap and its position count, uniform
@@ -414,7 +458,7 @@ conv_gemm_kernel(const GemmParams p)
             k_end = min(p.Kc, k_begin + p.split_len);
 #pragma unroll
             for (int i = 0; i < BV; ++i) {
-                const int m = k_begin + wb_k + B_RPP * i;
+                const int m = k_begin + b_krow(i);
                 const int n = m / (p.gp * p.gq);
                 const int rem = m - n * (p.gp * p.gq);
                 pn[i] = n;
@@ -502,7 +546,7 @@ conv_gemm_kernel(const GemmParams p)
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int k = m0 + wa_c4 * 4;
-            a_base[i] = k < p.M ? (unsigned)((wa_k + A_RPP * i) * p.ldg + k) : kBad;
+            a_base[i] = k < p.M ? (unsigned)(a_krow(i) * p.ldg + k) : kBad;
         }
     }
     const int RS = p.R * p.S;
@@ -580,14 +624,14 @@ conv_gemm_kernel(const GemmParams p)
             const unsigned gofs = (unsigned)(kb * p.ldg);
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
-                const int m = kb + wa_k + A_RPP * i;
+                const int m = kb + a_krow(i);
                 const unsigned off = m < k_end ? 4u * (a_base[i] + gofs) : kOOB;
                 ra[i] = bload4(rA, off);
                 if (use_mask) rm[i] = bload4(rMask, off);
             }
 #pragma unroll
             for (int i = 0; i < BV; ++i) {
-                const int m = kb + wb_k + B_RPP * i;
+                const int m = kb + b_krow(i);
                 const int iy = py[i] * p.stride - p.pad + wr;
                 const int ix = px[i] * p.stride - p.pad + ws_;
                 const bool ok = wcol_ok && m < k_end && (unsigned)iy < (unsigned)p.sh &&
@@ -609,6 +653,60 @@ conv_gemm_kernel(const GemmParams p)
 
     // registers -> LDS; the fused epilogue-backward (ReLU mask, affine scale) is applied here
     auto store_slice = [&](int buf) {
+        if constexpr (SPLIT) {
+            unsigned short *pa = reinterpret_cast<unsigned short *>(smem[buf]);
+            unsigned short *pb = pa + 3 * PLA;
+            auto put = [&](unsigned short *plane0, int plane_len, int row, float4 v) {
+                unsigned h0, m0_, l0, h1, m1, l1;
+                split3(v.x, v.y, h0, m0_, l0);
+                split3(v.z, v.w, h1, m1, l1);
+                unsigned short *q = plane0 + row * SROW + kc_c4 * 4;
+                *reinterpret_cast<uint2 *>(q) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(q + plane_len) = make_uint2(m0_, m1);
+                *reinterpret_cast<uint2 *>(q + 2 * plane_len) = make_uint2(l0, l1);
+            };
+            if constexpr (MODE == WGRAD) {
+                // a thread holds 4 channels x 4 consecutive pixels: transposed in registers, one
+                // 8-byte write per channel and plane at [channel][pixel chunk ^ swz(channel)]
+                static_assert(AV == 4 && BV == 4, "SPLIT WGRAD: 128x128 tiles");
+                auto put_t = [&](unsigned short *plane0, int plane_len, int row0, int kchunk,
+                                 const float (&e)[4][4]) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        unsigned h0, m0_, l0, h1, m1, l1;
+                        split3(e[0][c], e[1][c], h0, m0_, l0);
+                        split3(e[2][c], e[3][c], h1, m1, l1);
+                        const int row = row0 + c;
+                        unsigned short *q = plane0 + row * SROW + ((kchunk ^ swz(row)) << 2);
+                        *reinterpret_cast<uint2 *>(q) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2 *>(q + plane_len) = make_uint2(m0_, m1);
+                        *reinterpret_cast<uint2 *>(q + 2 * plane_len) = make_uint2(l0, l1);
+                    }
+                };
+                float ea[4][4], eb[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float4 v = ra[i];
+                    if (HAS_MASK && use_mask) v = relu_mask(v, rm[i]);
+                    if (HAS_MASK && use_scale) v = mul4(v, rscale);
+                    ea[i][0] = v.x; ea[i][1] = v.y; ea[i][2] = v.z; ea[i][3] = v.w;
+                    eb[i][0] = rb[i].x; eb[i][1] = rb[i].y; eb[i][2] = rb[i].z; eb[i][3] = rb[i].w;
+                }
+                put_t(pa, PLA, wa_c4 * 4, wa_k, ea);
+                put_t(pb, PLB, wb_c4 * 4, wb_k, eb);
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                float4 v = ra[i];
+                if (HAS_MASK && use_mask) v = relu_mask(v, rm[i]);
+                if (HAS_MASK && use_scale) v = mul4(v, rscale);
+                put(pa, PLA, kc_row + KC_RPP * i, v);
+            }
+#pragma unroll
+            for (int i = 0; i < BV; ++i) put(pb, PLB, kc_row + KC_RPP * i, rb[i]);
+            return;
+        }
         float *sa = smem[buf];
         float *sb = smem[buf] + C_::A_FLOATS;
 #pragma unroll
@@ -673,6 +771,43 @@ conv_gemm_kernel(const GemmParams p)
 
     // one K slice: fragments of block kb+1 are fetched while block kb's MFMAs issue
     auto compute = [&](int buf) {
+        if constexpr (SPLIT) {
+            const unsigned short *pa = reinterpret_cast<const unsigned short *>(smem[buf]);
+            const unsigned short *pb = pa + 3 * PLA;
+            bf16x8 fa[2][TM][3], fb[2][TN][3];
+            auto frag = [&](int ks, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        a[i][q] = *reinterpret_cast<const bf16x8 *>(
+                            pa + q * PLA + (wm * (32 * TM) + i * 32 + li) * SROW +
+                            (((ks * 4 + lk * 2) ^ swz(wm * (32 * TM) + i * 32 + li)) << 2));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        b[j][q] = *reinterpret_cast<const bf16x8 *>(
+                            pb + q * PLB + (wn * (32 * TN) + j * 32 + li) * SROW +
+                            (((ks * 4 + lk * 2) ^ swz(wn * (32 * TN) + j * 32 + li)) << 2));
+            };
+            frag(0, fa[0], fb[0]);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if (ks + 1 < BK / 16) frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                // smallest terms first: (hi,lo) (lo,hi) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+                constexpr int QA[6] = {0, 2, 1, 1, 0, 0}, QB[6] = {2, 0, 1, 0, 1, 0};
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                fa[ks & 1][i][QA[c]], fb[ks & 1][j][QB[c]], acc[i][j], 0, 0, 0);
+            }
+            return;
+        }
         const float *sa = smem[buf];
         const float *sb = smem[buf] + C_::A_FLOATS;
         float af[2][TM][4], bf[2][TN][4];
@@ -1161,6 +1296,7 @@ constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
 int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM launch (lowers
                        // the resident workgroups per CU for co-residency experiments)
 
+int g_split_bf16 = 0;  // mrcnn_set_tuning("split_bf16", 0/1): opt-in split-operand kernel (see SPLIT)
 int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal start-up stagger; 0 = off)
 int g_stagger_min_rounds = 2;
 
@@ -1189,9 +1325,23 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
             p.stagger_cycles = (int)std::min<int64_t>(cyc, 1 << 20);
         }
     }
+    if constexpr (MODE == WGRAD && TM == 2 && TN == 2) {
+        if (g_split_bf16 && p.perm_n == 0) {
+            hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
+                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
+            return;
+        }
+    }
     if constexpr (MODE == WGRAD && !MASKED) {
         if (p.perm_n > 0) {
             hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
+                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
+            return;
+        }
+    }
+    if constexpr (MODE == FWD && TM == 2 && TN == 2) {
+        if (g_split_bf16) {
+            hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
                                dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
             return;
         }
@@ -1581,6 +1731,10 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
         g_small_m_split = value;
         return 0;
     }
+    if (strcmp(name, "split_bf16") == 0) {
+        g_split_bf16 = value != 0;
+        return 0;
+    }
     if (strcmp(name, "stagger") == 0) {
         g_stagger = value;
         return 0;
@@ -1864,7 +2018,6 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     // the problem is at least one tile wide; otherwise 64x64 tiles.
     const int64_t small = mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
     const int64_t max_splits = std::min<int64_t>(64, std::max<int64_t>(1, pixels / (8 * BK)));
-    const int64_t slots_big = single_buffered(2, WGRAD, is_masked(p)) ? 768 : kSlotsBig;
     const bool use_big = p.N > 64 && p.M > 64 && big * max_splits * 2 >= kSlotsBig;
     const int64_t tiles = use_big ? big : small;
     // block-position-major pixel order (WPERM kernel): border taps skip the positions where
@@ -1872,6 +2025,9 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     if (C % (use_big ? 128 : 64) == 0 && N_ >= BK && !is_masked(p))
         p.perm_n = choose_perm(N_, P, Q, R, S, stride, pad);
     const int64_t k_extent = p.perm_n ? mrcnn::ceil_div(N_, BK) * BK * P * Q : pixels;
+    // resident 128x128 workgroups: 3 per CU single-buffered, 2 otherwise (and for the split-operand kernel)
+    const bool split_kernel = g_split_bf16 && p.perm_n == 0;
+    const int64_t slots_big = !split_kernel && single_buffered(2, WGRAD, is_masked(p)) ? 768 : kSlotsBig;
     int splits = wgrad_splits(tiles, pixels, use_big ? slots_big : kSlotsSmall);
     if (!ws) splits = 1;
     p.split_len = (int)(mrcnn::ceil_div(mrcnn::ceil_div(k_extent, splits), BK) * BK);
