@@ -152,7 +152,18 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # MRCNN_TUNE="name=value,...": mrcnn_set_tuning knobs applied when the library is loaded
+    # (e.g. MRCNN_TUNE=split_bf16=3 selects the opt-in split-operand GEMM kernels)
+    for kv in os.environ.get('MRCNN_TUNE', '').split(','):
+        if '=' in kv:
+            k, v = kv.split('=', 1)
+            set_tuning(k.strip(), int(v))
     return lib
+
+
+def set_tuning(name, value):
+    """mrcnn_set_tuning(name, value): kernel-selection knobs of libmrcnn_hip.so (include/mrcnn_hip.h)."""
+    check(load().mrcnn_set_tuning(name.encode(), int(value)), 'set_tuning(%s)' % name)
 
 
 def stream_ptr():

@@ -268,6 +268,10 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 }
 __device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &m, unsigned &l)
 {
+#ifdef MRCNN_DBG_NOSPLITVALU   // ablation: no conversion arithmetic (results are garbage)
+    h = __float_as_uint(a); m = __float_as_uint(b); l = h ^ m;
+    return;
+#endif
     h = pack_bf16(a, b);
     a -= __uint_as_float(h << 16);
     b -= __uint_as_float(h & 0xffff0000u);
@@ -297,12 +301,13 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &
 // measures the error against float64 next to the fp32 MFMA kernel's), while the matrix pipe
 // does 6 x 32 instead of 8 x 64 cycles per 32x32x16 block.
 template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false>
-__global__ void __launch_bounds__(256, SPLIT ? 2 : min_blocks(TM, MODE, MASKED))
+__global__ void __launch_bounds__(256, SPLIT ? (TM == 2 ? 2 : 4) : min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
-    static_assert(!SPLIT || ((MODE == FWD || (MODE == WGRAD && !WPERM)) && TM == 2 && TN == 2 && BK == 32),
-                  "SPLIT: 128x128 forward form / weight gradient only");
+    static_assert(!SPLIT || (BK == 32 && TM == TN &&
+                             ((MODE == FWD && (TM == 1 || TM == 2)) || (MODE == WGRAD && !WPERM && TM == 2))),
+                  "SPLIT: forward form (128x128, 64x64) / weight gradient (128x128) only");
     constexpr bool SINGLEBUF = SPLIT || single_buffered(TM, MODE, MASKED);
     using C_ = Cfg<TM, TN, MODE>;
     constexpr int BM = C_::BM, BN = C_::BN;
@@ -548,13 +553,43 @@ conv_gemm_kernel(const GemmParams p)
             const int k = m0 + wa_c4 * 4;
             a_base[i] = k < p.M ? (unsigned)(a_krow(i) * p.ldg + k) : kBad;
         }
+        if (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < BV; ++i)
+                b_base[i] = wcol_ok ? (unsigned)(b_krow(i) * p.lda + wc) : kBad;
+        }
     }
+    const bool wpoint = MODE == WGRAD && !WPERM && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 &&
+                        p.gp == p.sh && p.gq == p.sw;      // uniform
     const int RS = p.R * p.S;
 
     // issue the global loads of slice kt (nothing here consumes a loaded value).
     // FWD/DGRAD K order: channel chunk outer, filter tap (r,s) inner — consecutive slices re-read
     // the same 32-channel slab of neighbouring pixels, which stays in the CU's L1.
     auto load_slice = [&](int kt) {
+        if (SPLIT && FWDLIKE && pointwise) {
+            // (split-operand kernels only: the fp32 kernels sit at their register budget)
+            // 1x1 / stride 1: slice kt is channel chunk kt of the row's own pixel — none of the
+            // tap / chunk divisions and bounds checks of the general gather (a quarter of the
+            // instructions a wave issues per slice, all of them competing with the MFMAs of the
+            // co-resident waves for issue slots)
+            const int c0 = (kt + kt0) * BK;
+            const int cc = c0 + kc_c4 * 4;
+            const bool c_ok = cc < p.Kc;
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                const unsigned off = (c_ok && a_y[i] == 0) ? 4u * (a_base[i] + (unsigned)c0) : kOOB;
+                ra[i] = bload4(rA, off);
+                if (HAS_MASK && use_mask) rm[i] = bload4(rMask, off);
+            }
+            if (HAS_MASK && use_scale)
+                rscale = c_ok ? *reinterpret_cast<const float4 *>(p.in_scale + cc)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < BV; ++i)
+                rb[i] = bload4(rB, c_ok ? 4u * (b_base[i] + (unsigned)c0) : kOOB);
+            return;
+        }
         if (FWDLIKE || MODE == DGRAD) {
             kt += kt0;
             int chunk, rs;
@@ -628,6 +663,16 @@ conv_gemm_kernel(const GemmParams p)
                 const unsigned off = m < k_end ? 4u * (a_base[i] + gofs) : kOOB;
                 ra[i] = bload4(rA, off);
                 if (use_mask) rm[i] = bload4(rMask, off);
+            }
+            if (SPLIT && wpoint) {
+                // 1x1 / stride 1: pixel m of gy is pixel m of x
+                const unsigned xofs = (unsigned)(kb * p.lda);
+#pragma unroll
+                for (int i = 0; i < BV; ++i) {
+                    const int m = kb + b_krow(i);
+                    rb[i] = bload4(rB, m < k_end ? 4u * (b_base[i] + xofs) : kOOB);
+                }
+                return;
             }
 #pragma unroll
             for (int i = 0; i < BV; ++i) {
@@ -1326,7 +1371,7 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
         }
     }
     if constexpr (MODE == WGRAD && TM == 2 && TN == 2) {
-        if (g_split_bf16 && p.perm_n == 0) {
+        if ((g_split_bf16 & 1) && p.perm_n == 0) {
             hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
                                dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
             return;
@@ -1339,8 +1384,8 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
             return;
         }
     }
-    if constexpr (MODE == FWD && TM == 2 && TN == 2) {
-        if (g_split_bf16) {
+    if constexpr (MODE == FWD && TM == TN && (TM == 1 || TM == 2)) {
+        if (g_split_bf16 & (TM == 2 ? 1 : 2)) {
             hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
                                dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
             return;
@@ -1536,6 +1581,7 @@ void launch_remainder(const GemmParams &p, int rows_lo, hipStream_t s)
 
 extern float g_wino_ambiguity;
 int g_small_whole_max = 1024, g_small_rem_max = 154;   // developer knobs (A/B)
+int g_big_min_tiles = 384;        // mrcnn_set_tuning("big_min_tiles"): fewest 128x128 tiles that get 128x128 tiles
 int g_small_m_split = 0;          // mrcnn_set_tuning("small_m_split", target workgroups per CU)
 
 template <int MODE>
@@ -1588,7 +1634,7 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
     const int64_t tm = mrcnn::ceil_div(p.M, 128), tn = mrcnn::ceil_div(p.N, 128);
     const int64_t T = tm * tn;
     const bool big_ok = p.N > 64 && p.M > 64;
-    if (!big_ok || T < 384) {
+    if (!big_ok || T < g_big_min_tiles) {
         launch_small<MODE>(p, s);
     } else {
         // whole "rounds" of k workgroups per CU (k = 3, 2, 1): pick the round size that leaves
@@ -1719,6 +1765,10 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
         g_wino_ambiguity = 1e-9f * (float)value;
         return 0;
     }
+    if (strcmp(name, "big_min_tiles") == 0) {
+        g_big_min_tiles = value;
+        return 0;
+    }
     if (strcmp(name, "small_whole_max") == 0) {
         g_small_whole_max = value;
         return 0;
@@ -1732,7 +1782,7 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
         return 0;
     }
     if (strcmp(name, "split_bf16") == 0) {
-        g_split_bf16 = value != 0;
+        g_split_bf16 = value;          // bit 0: 128x128 kernels, bit 1: 64x64 forward form
         return 0;
     }
     if (strcmp(name, "stagger") == 0) {
@@ -2018,7 +2068,7 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
     // the problem is at least one tile wide; otherwise 64x64 tiles.
     const int64_t small = mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
     const int64_t max_splits = std::min<int64_t>(64, std::max<int64_t>(1, pixels / (8 * BK)));
-    const bool use_big = p.N > 64 && p.M > 64 && big * max_splits * 2 >= kSlotsBig;
+    const bool use_big = p.N > 64 && p.M > 64 && (big * max_splits * 2 >= kSlotsBig || g_big_min_tiles <= 1);
     const int64_t tiles = use_big ? big : small;
     // block-position-major pixel order (WPERM kernel): border taps skip the positions where
     // they fall into the padding; the reduction then runs over whole blocks of BK images
@@ -2026,7 +2076,7 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
         p.perm_n = choose_perm(N_, P, Q, R, S, stride, pad);
     const int64_t k_extent = p.perm_n ? mrcnn::ceil_div(N_, BK) * BK * P * Q : pixels;
     // resident 128x128 workgroups: 3 per CU single-buffered, 2 otherwise (and for the split-operand kernel)
-    const bool split_kernel = g_split_bf16 && p.perm_n == 0;
+    const bool split_kernel = (g_split_bf16 & 1) && p.perm_n == 0;
     const int64_t slots_big = !split_kernel && single_buffered(2, WGRAD, is_masked(p)) ? 768 : kSlotsBig;
     int splits = wgrad_splits(tiles, pixels, use_big ? slots_big : kSlotsSmall);
     if (!ws) splits = 1;

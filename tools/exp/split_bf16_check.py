@@ -17,6 +17,11 @@ SHAPES = [('res5 1x1 512->2048', 1024, 512, 7, 7, 2048, 1, 1, 0),
           ('rpn 3x3 1024', 2, 1024, 51, 84, 1024, 3, 1, 1)]
 
 
+if os.environ.get('CHECK_SHAPES'):      # "name:N:C:H:W:K:k:s:p;..."
+    SHAPES = [tuple([f.split(':')[0]] + [int(v) for v in f.split(':')[1:]])
+              for f in os.environ['CHECK_SHAPES'].split(';')]
+
+
 def timeit(fn, iters=10):
     for _ in range(2):
         fn()
