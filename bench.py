@@ -379,6 +379,8 @@ def main():
     ap.add_argument('--defer-wgrad', type=int, default=5,
                     help='number of res5 weight gradients (a.conv2, a.conv1, a.conv3, a.conv4, b1.conv2, ...) held back into the '
                          "next step's proposal window (single-GPU runs; 0 = off)")
+    ap.add_argument('--no-split-bf16', dest='split_bf16', action='store_false',
+                    help='skip the extra measurement on the opt-in split-operand (3 x bf16) GEMM kernels')
     ap.add_argument('--tune', default='',
                     help='developer: comma-separated mrcnn_set_tuning knobs, e.g. small_m_split=4')
     ap.add_argument('--bucket-mb', type=float, default=16.0,
@@ -608,6 +610,29 @@ def main():
                                  'F(4x4,3x3) route (the default up to round 2; DESIGN.md section 4.3)',
                         loss=round(float(loss_w.item()), 5))
 
+    # ---- the same step on the opt-in split-operand GEMM kernels ----------
+    split_run = None
+    if args.split_bf16:
+        from chainer_mask_rcnn_amd.functions import conv as conv_mod
+        conv_mod.set_gemm_arithmetic('split_bf16x3')
+        for _ in range(max(2, args.warmup)):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_s = step()
+        fence()
+        el_s = max_over_ranks(time.perf_counter() - t0)
+        conv_mod.set_gemm_arithmetic('fp32')
+        split_run = dict(value=round(args.steps * args.batch * world / el_s, 3), unit='images/sec',
+                         ms_per_step=round(el_s / args.steps * 1e3, 3),
+                         workload="same step, functions.conv.set_gemm_arithmetic('split_bf16x3'): the "
+                                  'forward-form and 128x128 weight-gradient GEMMs stage every fp32 operand '
+                                  'as three exact bf16 planes and run six bf16 MFMAs per K step with fp32 '
+                                  'accumulation (error against float64 at the fp32 kernel\'s level, '
+                                  'tests/test_gpu_split_bf16.py); opt-in, NOT the headline value',
+                         loss=round(float(loss_s.item()), 5))
+
     # ---- third measurement: the same step fed by the train loop's input pipeline ----------------
     pipeline = None
     if args.pipeline_examples > 0:
@@ -729,6 +754,8 @@ def main():
             out['device_targets'] = dev_targets
         if wino_fwd is not None:
             out['direct_head_forward'] = wino_fwd
+        if split_run is not None:
+            out['split_bf16x3'] = split_run
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         emit_json(out)

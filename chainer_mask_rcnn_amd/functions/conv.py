@@ -437,6 +437,27 @@ def _wino_ws(d, device, tag='wino'):
 _wino_u_cache = {}
 
 
+# ---- arithmetic of the convolution GEMMs ----------------------------------------------------
+# 'fp32' (default): exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  'split_bf16x3' (opt-in): every
+# operand element is split EXACTLY into three bf16 values (8 + 8 + 8 significand bits) while it is
+# staged, and a K step runs six bf16 MFMAs (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) with fp32
+# accumulation; the dropped cross terms are <= 2^-24 of a product each, so the result carries the
+# error of an fp32 GEMM (tests/test_gpu_split_bf16.py: measured against float64 next to the fp32
+# kernel) at 2.7x the matrix-pipe rate.  Covers the forward-form kernels (forward, stride-1 data
+# gradient, the Winograd per-frequency GEMMs) and the 128x128 weight gradient; everything else
+# (strided data gradient, position-major weight gradient, 64x64 weight gradient) stays on fp32 MFMA.
+GEMM_ARITHMETIC = 'fp32'
+
+
+def set_gemm_arithmetic(kind):
+    """Select 'fp32' or 'split_bf16x3' for the convolution GEMM kernels (process-wide)."""
+    global GEMM_ARITHMETIC
+    if kind not in ('fp32', 'split_bf16x3'):
+        raise ValueError("gemm arithmetic must be 'fp32' or 'split_bf16x3', got %r" % (kind,))
+    _lib.set_tuning('split_bf16', 3 if kind == 'split_bf16x3' else 0)
+    GEMM_ARITHMETIC = kind
+
+
 def weights_changed():
     """Public invalidation call: parameters were written outside torch's version tracking — the
     SGD kernel updates the flat arena through a raw pointer; user code that writes through
