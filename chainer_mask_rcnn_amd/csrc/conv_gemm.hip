@@ -553,7 +553,7 @@ conv_gemm_kernel(const GemmParams p)
             const int k = m0 + wa_c4 * 4;
             a_base[i] = k < p.M ? (unsigned)(a_krow(i) * p.ldg + k) : kBad;
         }
-        if (SPLIT) {
+        if (!WPERM) {
 #pragma unroll
             for (int i = 0; i < BV; ++i)
                 b_base[i] = wcol_ok ? (unsigned)(b_krow(i) * p.lda + wc) : kBad;
@@ -567,8 +567,7 @@ conv_gemm_kernel(const GemmParams p)
     // FWD/DGRAD K order: channel chunk outer, filter tap (r,s) inner — consecutive slices re-read
     // the same 32-channel slab of neighbouring pixels, which stays in the CU's L1.
     auto load_slice = [&](int kt) {
-        if (SPLIT && FWDLIKE && pointwise) {
-            // (split-operand kernels only: the fp32 kernels sit at their register budget)
+        if (FWDLIKE && pointwise) {
             // 1x1 / stride 1: slice kt is channel chunk kt of the row's own pixel — none of the
             // tap / chunk divisions and bounds checks of the general gather (a quarter of the
             // instructions a wave issues per slice, all of them competing with the MFMAs of the
@@ -664,7 +663,7 @@ conv_gemm_kernel(const GemmParams p)
                 ra[i] = bload4(rA, off);
                 if (use_mask) rm[i] = bload4(rMask, off);
             }
-            if (SPLIT && wpoint) {
+            if (wpoint) {
                 // 1x1 / stride 1: pixel m of gy is pixel m of x
                 const unsigned xofs = (unsigned)(kb * p.lda);
 #pragma unroll
