@@ -315,7 +315,11 @@ conv_gemm_kernel(const GemmParams p)
     constexpr bool HAS_MASK = MASKED;
     constexpr bool FWDLIKE = is_fwd(MODE);
     // SPLIT stage: 3 planes per operand of [row][32 bf16 + 8 pad] (80-byte rows: conflict-free b128)
-    constexpr int SROW = BK + 8;                          // ushorts per plane row
+    // forward form: 64-byte rows, 16-byte slots XOR-swizzled by (row >> 2) & 3 — conflict-free for
+    // the b128 fragment reads (lane groups {0-3,12-15,20-27}, ...) AND for the b64 plane writes (a
+    // 16-lane group writes two whole rows = one 128-byte bank row).  Weight gradient: 80-byte rows
+    // (its transposing writes hit rows 4 apart; see swz).
+    constexpr int SROW = MODE == WGRAD ? BK + 8 : BK;     // ushorts per plane row
     constexpr int PLA = BM * SROW, PLB = BN * SROW;       // ushorts per plane
     constexpr int STAGE_FLOATS = SPLIT ? 3 * (PLA + PLB) / 2 : C_::A_FLOATS + C_::B_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem_all[1][SINGLEBUF ? 1 : 2][STAGE_FLOATS];
@@ -324,7 +328,7 @@ conv_gemm_kernel(const GemmParams p)
     // SPLIT WGRAD: the 8-byte chunk index inside a plane row is XORed with an EVEN number that
     // depends on the row's group of 16 (16-byte pairs stay together for the b128 fragment reads);
     // the transposing writes of one instruction hit rows 4 apart, which would otherwise share banks
-    auto swz = [](int row) { return (SPLIT && MODE == WGRAD) ? ((row >> 4) & 3) << 1 : 0; };
+    auto swz = [](int row) { return !SPLIT ? 0 : MODE == WGRAD ? ((row >> 4) & 3) << 1 : ((row >> 2) & 3) << 1; };
     const int tid = threadIdx.x;
 #ifdef MRCNN_GEMM_CLOCKPROBE
     const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime();
@@ -704,7 +708,7 @@ conv_gemm_kernel(const GemmParams p)
                 unsigned h0, m0_, l0, h1, m1, l1;
                 split3(v.x, v.y, h0, m0_, l0);
                 split3(v.z, v.w, h1, m1, l1);
-                unsigned short *q = plane0 + row * SROW + kc_c4 * 4;
+                unsigned short *q = plane0 + row * SROW + ((kc_c4 ^ swz(row)) << 2);
                 *reinterpret_cast<uint2 *>(q) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2 *>(q + plane_len) = make_uint2(m0_, m1);
                 *reinterpret_cast<uint2 *>(q + 2 * plane_len) = make_uint2(l0, l1);
