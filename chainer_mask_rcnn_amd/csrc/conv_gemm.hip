@@ -266,6 +266,18 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
     const f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+// a - b as ONE v_sub_f32: left to the compiler, adjacent subtractions are packed into v_pk_add_f32,
+// which costs far more than its issue slot beside MFMAs (MI355X_MICROARCH.md, filler prices)
+__device__ __forceinline__ float sub_f32(float a, float b)
+{
+#ifdef MRCNN_SPLIT_PK_SUB
+    return a - b;
+#else
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
 __device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &m, unsigned &l)
 {
 #ifdef MRCNN_DBG_NOSPLITVALU   // ablation: no conversion arithmetic (results are garbage)
@@ -273,11 +285,11 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &
     return;
 #endif
     h = pack_bf16(a, b);
-    a -= __uint_as_float(h << 16);
-    b -= __uint_as_float(h & 0xffff0000u);
+    a = sub_f32(a, __uint_as_float(h << 16));
+    b = sub_f32(b, __uint_as_float(h & 0xffff0000u));
     m = pack_bf16(a, b);
-    a -= __uint_as_float(m << 16);
-    b -= __uint_as_float(m & 0xffff0000u);
+    a = sub_f32(a, __uint_as_float(m << 16));
+    b = sub_f32(b, __uint_as_float(m & 0xffff0000u));
     l = pack_bf16(a, b);
 }
 
@@ -752,7 +764,18 @@ conv_gemm_kernel(const GemmParams p)
                 put(pa, PLA, kc_row + KC_RPP * i, v);
             }
 #pragma unroll
-            for (int i = 0; i < BV; ++i) put(pb, PLB, kc_row + KC_RPP * i, rb[i]);
+            for (int i = 0; i < BV; ++i) {
+#ifdef MRCNN_DBG_NOSPLIT_B    // ablation: the B operand costs no conversion (results are garbage)
+                const int row = kc_row + KC_RPP * i;
+                unsigned short *q = pb + row * SROW + ((kc_c4 ^ swz(row)) << 2);
+                const uint2 u = make_uint2(__float_as_uint(rb[i].x), __float_as_uint(rb[i].y));
+                *reinterpret_cast<uint2 *>(q) = u;
+                *reinterpret_cast<uint2 *>(q + PLB) = make_uint2(__float_as_uint(rb[i].z), __float_as_uint(rb[i].w));
+                *reinterpret_cast<uint2 *>(q + 2 * PLB) = u;
+#else
+                put(pb, PLB, kc_row + KC_RPP * i, rb[i]);
+#endif
+            }
             return;
         }
         float *sa = smem[buf];
