@@ -618,15 +618,17 @@ def main():
     if args.split_bf16:
         from chainer_mask_rcnn_amd.functions import conv as conv_mod
         conv_mod.set_gemm_arithmetic('split_bf16x3')
-        for _ in range(max(2, args.warmup)):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss_s = step()
-        fence()
-        el_s = max_over_ranks(time.perf_counter() - t0)
-        conv_mod.set_gemm_arithmetic('fp32')
+        try:
+            for _ in range(max(2, args.warmup)):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss_s = step()
+            fence()
+            el_s = max_over_ranks(time.perf_counter() - t0)
+        finally:
+            conv_mod.set_gemm_arithmetic('fp32')
         split_run = dict(value=round(args.steps * args.batch * world / el_s, 3), unit='images/sec',
                          ms_per_step=round(el_s / args.steps * 1e3, 3),
                          workload="same step, functions.conv.set_gemm_arithmetic('split_bf16x3'): the "

@@ -155,9 +155,17 @@ def load():
     # MRCNN_TUNE="name=value,...": mrcnn_set_tuning knobs applied when the library is loaded
     # (e.g. MRCNN_TUNE=split_bf16=3 selects the opt-in split-operand GEMM kernels)
     for kv in os.environ.get('MRCNN_TUNE', '').split(','):
-        if '=' in kv:
-            k, v = kv.split('=', 1)
-            set_tuning(k.strip(), int(v))
+        if not kv.strip():
+            continue
+        k, sep, v = kv.partition('=')
+        try:
+            value = int(v)
+        except ValueError:
+            sep = ''
+        if not sep:
+            _lib = None
+            raise MrcnnHipError("MRCNN_TUNE: expected 'name=integer[,name=integer...]', got %r" % kv)
+        set_tuning(k.strip(), value)
     return lib
 
 

@@ -106,3 +106,20 @@ def test_bench_refuses_more_ranks_than_devices():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert 'ROCm device(s) visible' in r.stderr and r.stdout.strip() == ''
+
+
+def test_kernel_selection_switches_without_device(lib):
+    """mrcnn_set_tuning: the arithmetic switch of the GEMM kernels and the host mirror's wrapper."""
+    from chainer_mask_rcnn_amd import _lib
+    from chainer_mask_rcnn_amd.functions import conv
+    assert lib.mrcnn_set_tuning(b'split_bf16', 0) == 0
+    rc = lib.mrcnn_set_tuning(b'no_such_switch', 1)
+    assert rc != 0 and b'unknown option' in lib.mrcnn_last_error()
+    with pytest.raises(_lib.MrcnnHipError):
+        _lib.set_tuning('no_such_switch', 1)
+    with pytest.raises(ValueError):
+        conv.set_gemm_arithmetic('bf16')
+    conv.set_gemm_arithmetic('split_bf16x3')
+    assert conv.GEMM_ARITHMETIC == 'split_bf16x3'
+    conv.set_gemm_arithmetic('fp32')
+    assert conv.GEMM_ARITHMETIC == 'fp32'
