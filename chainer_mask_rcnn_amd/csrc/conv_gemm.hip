@@ -1665,7 +1665,9 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
     } else {
         // whole "rounds" of k workgroups per CU (k = 3, 2, 1): pick the round size that leaves
         // the smallest leftover, run the leftover rows as 64x64 tiles
-        const int64_t max_per_cu = single_buffered(2, MODE, is_masked(p)) ? 3 : 2;
+        // resident 128x128 workgroups per CU: 3 single-buffered fp32, 2 otherwise (and split-operand)
+        const bool split_fwd = MODE == FWD && (g_split_bf16 & 1);
+        const int64_t max_per_cu = !split_fwd && single_buffered(2, MODE, is_masked(p)) ? 3 : 2;
         int64_t main_tiles_m = tm, best_rem = T;
         for (int64_t k = max_per_cu; k >= 1; --k) {
             const int64_t slots = 256 * k, full = T / slots, rem = T - full * slots;
