@@ -3,10 +3,10 @@
 // Replaces the two CuPy kernel strings of the reference
 // (/root/reference/chainer_mask_rcnn/functions/roi_align_2d.py:171-288 fwd,
 // :395-522 bwd), which run one thread per NCHW output element with
-// uncoalesced 4-tap gathers.  Here one workgroup owns one output bin
-// (roi, ph, pw): all sample geometry is wave-uniform (SGPR) arithmetic derived
+// uncoalesced 4-tap gathers.  Here one workgroup owns one output row of a RoI
+// (roi, ph, all pw): all sample geometry is wave-uniform arithmetic derived
 // from blockIdx, and the lanes run across channels, so every tap is a
-// contiguous 16 B/lane read of the NHWC feature row and the result is one
+// contiguous 16 B/lane read of the NHWC feature row and every result one
 // contiguous 16 B/lane store.  HBM-bound: the forward writes R*PH*PW*C*4 bytes.
 //
 // Built with -ffp-contract=off and the reference's operation order so that the
@@ -70,6 +70,15 @@ __device__ __forceinline__ Tap1D tap1d(float p, int size)
     return t;
 }
 
+// Streaming stores for the pooled output (written once, read by the next kernel after 200 MB of
+// other traffic): keeps the feature map's taps resident in L2.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void store_stream(float4 *p, float4 v)
+{
+    __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(p));
+}
+
 template <typename V> struct VecOps;
 template <> struct VecOps<float> {
     static __device__ __forceinline__ float zero() { return 0.f; }
@@ -98,43 +107,116 @@ template <> struct VecOps<float4> {
     }
 };
 
-// V = float4 when C % 4 == 0 (CV = C/4 vectors per pixel), else float.
-template <typename V>
-__global__ void roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois,
-                                     V *__restrict__ y, int H, int W, int CV, int PH, int PW,
-                                     float spatial_scale, int sampling_ratio, int OH, int OW,
-                                     int BS)
+// GH x GW samples of NB consecutive bins of one output row, all taps loaded before the first
+// is used (NB * GH * GW * 4 independent 16 B loads in flight per lane), then accumulated in the
+// reference's order.  Tap coordinates are clamped into the map even for samples the reference
+// skips (tap1d), so the loads need no branch; the skip guards the accumulation only.
+template <typename V, int GH, int GW, int NB>
+__device__ __forceinline__ void fwd_bins(const V *__restrict__ img, V *__restrict__ out,
+                                         const RoiGeom &g, int ph, int ow0, int OW, int BS, int H,
+                                         int W, int CV)
 {
-    // output bin (oh, ow) is bin (oh*BS, ow*BS) of the PH x PW grid (BS = 1: every bin)
-    const int bin = blockIdx.x;  // ((n*OH)+oh)*OW+ow
-    const int pw = (bin % OW) * BS;
-    const int ph = ((bin / OW) % OH) * BS;
-    const int n = bin / (OW * OH);
-    const RoiGeom g = roi_geom(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio);
-    const V *__restrict__ img = x + (int64_t)g.batch * H * W * CV;
-    V *__restrict__ out = y + (int64_t)bin * CV;
-
-    for (int c = threadIdx.x; c < CV; c += blockDim.x) {
-        V acc = VecOps<V>::zero();
-        for (int iy = 0; iy < g.grid_h; ++iy) {
-            const float yy = g.start_h + ph * g.bin_h +
-                             (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
+    constexpr int S = GH * GW;
+    V v[NB][S][4];
+    float wt[NB][S][4];
+    bool ok[NB][S];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (ow0 + b >= OW) break;
+        const int pw = (ow0 + b) * BS;
+#pragma unroll
+        for (int iy = 0; iy < GH; ++iy) {
+            const float yy = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
             const Tap1D ty = tap1d(yy, H);
-            for (int ix = 0; ix < g.grid_w; ++ix) {
+#pragma unroll
+            for (int ix = 0; ix < GW; ++ix) {
                 const float xx = g.start_w + pw * g.bin_w +
                                  (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
                 const Tap1D tx = tap1d(xx, W);
-                if (!(ty.valid && tx.valid)) continue;
-                const float w1 = ty.h * tx.h, w2 = ty.h * tx.l;
-                const float w3 = ty.l * tx.h, w4 = ty.l * tx.l;
-                const V v1 = img[((int64_t)ty.lo * W + tx.lo) * CV + c];
-                const V v2 = img[((int64_t)ty.lo * W + tx.hi) * CV + c];
-                const V v3 = img[((int64_t)ty.hi * W + tx.lo) * CV + c];
-                const V v4 = img[((int64_t)ty.hi * W + tx.hi) * CV + c];
-                acc = VecOps<V>::mad4(acc, w1, v1, w2, v2, w3, v3, w4, v4);
+                const int s = iy * GW + ix;
+                ok[b][s] = ty.valid && tx.valid;
+                wt[b][s][0] = ty.h * tx.h;
+                wt[b][s][1] = ty.h * tx.l;
+                wt[b][s][2] = ty.l * tx.h;
+                wt[b][s][3] = ty.l * tx.l;
+                v[b][s][0] = img[((int64_t)ty.lo * W + tx.lo) * CV];
+                v[b][s][1] = img[((int64_t)ty.lo * W + tx.hi) * CV];
+                v[b][s][2] = img[((int64_t)ty.hi * W + tx.lo) * CV];
+                v[b][s][3] = img[((int64_t)ty.hi * W + tx.hi) * CV];
             }
         }
-        out[c] = VecOps<V>::div(acc, g.count);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (ow0 + b >= OW) break;
+        V acc = VecOps<V>::zero();
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (ok[b][s])
+                acc = VecOps<V>::mad4(acc, wt[b][s][0], v[b][s][0], wt[b][s][1], v[b][s][1],
+                                      wt[b][s][2], v[b][s][2], wt[b][s][3], v[b][s][3]);
+        store_stream(&out[(int64_t)(ow0 + b) * CV], VecOps<V>::div(acc, g.count));
+    }
+}
+
+// V = float4 when C % 4 == 0 (CV = C/4 vectors per pixel), else float.
+// One workgroup owns one output ROW of a RoI (OW bins): a workgroup per bin (the first version)
+// lived for one RoI read + four dependent-latency loads + one store and was bound by that
+// turnaround (0.24 of the HBM peak with 4 taps per bin); here the taps of up to four bins are in
+// flight together.  The sampling grid is a property of the RoI, so the choice among the
+// unrolled bodies is workgroup-uniform.
+template <typename V>
+__global__ void __launch_bounds__(256)
+roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois, V *__restrict__ y,
+                     int H, int W, int CV, int PH, int PW, float spatial_scale, int sampling_ratio,
+                     int OH, int OW, int BS, int rows)
+{
+    // output bin (oh, ow) is bin (oh*BS, ow*BS) of the PH x PW grid (BS = 1: every bin)
+    // an XCD (workgroup id mod 8) owns a contiguous run of rows (n*OH + oh): the OH rows of a
+    // RoI, which re-read each other's taps, share one L2
+    const int per = ((int)gridDim.x + 7) / 8;
+    const int row = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if (row >= rows) return;
+    const int ph = (row % OH) * BS;
+    const int n = row / OH;
+    const RoiGeom g = roi_geom(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio);
+
+    for (int c = threadIdx.x; c < CV; c += blockDim.x) {
+        const V *__restrict__ img = x + (int64_t)g.batch * H * W * CV + c;
+        V *__restrict__ out = y + (int64_t)row * OW * CV + c;
+        if (g.grid_h == 1 && g.grid_w == 1) {
+            for (int ow0 = 0; ow0 < OW; ow0 += 4) fwd_bins<V, 1, 1, 4>(img, out, g, ph, ow0, OW, BS, H, W, CV);
+        } else if (g.grid_h == 1 && g.grid_w == 2) {
+            for (int ow0 = 0; ow0 < OW; ow0 += 2) fwd_bins<V, 1, 2, 2>(img, out, g, ph, ow0, OW, BS, H, W, CV);
+        } else if (g.grid_h == 2 && g.grid_w == 1) {
+            for (int ow0 = 0; ow0 < OW; ow0 += 2) fwd_bins<V, 2, 1, 2>(img, out, g, ph, ow0, OW, BS, H, W, CV);
+        } else if (g.grid_h == 2 && g.grid_w == 2) {
+            for (int ow0 = 0; ow0 < OW; ++ow0) fwd_bins<V, 2, 2, 1>(img, out, g, ph, ow0, OW, BS, H, W, CV);
+        } else {
+            for (int ow_ = 0; ow_ < OW; ++ow_) {
+                const int pw = ow_ * BS;
+                V acc = VecOps<V>::zero();
+                for (int iy = 0; iy < g.grid_h; ++iy) {
+                    const float yy = g.start_h + ph * g.bin_h +
+                                     (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
+                    const Tap1D ty = tap1d(yy, H);
+                    for (int ix = 0; ix < g.grid_w; ++ix) {
+                        const float xx = g.start_w + pw * g.bin_w +
+                                         (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
+                        const Tap1D tx = tap1d(xx, W);
+                        if (!(ty.valid && tx.valid)) continue;
+                        const float w1 = ty.h * tx.h, w2 = ty.h * tx.l;
+                        const float w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+                        const V v1 = img[((int64_t)ty.lo * W + tx.lo) * CV];
+                        const V v2 = img[((int64_t)ty.lo * W + tx.hi) * CV];
+                        const V v3 = img[((int64_t)ty.hi * W + tx.lo) * CV];
+                        const V v4 = img[((int64_t)ty.hi * W + tx.hi) * CV];
+                        acc = VecOps<V>::mad4(acc, w1, v1, w2, v2, w3, v3, w4, v4);
+                    }
+                }
+                store_stream(&out[(int64_t)ow_ * CV], VecOps<V>::div(acc, g.count));
+            }
+        }
     }
 }
 
@@ -296,16 +378,28 @@ roi_align_bwd_gather_kernel(const V *__restrict__ gy, const float *__restrict__ 
 // The gather form above still issues one atomic per (RoI patch pixel, channel): ~1.7e8 float
 // atomics at the C2 shape, which bound it at 1.35 ms.  Here every feature-map pixel is OWNED
 // by one workgroup, which sums the contributions of all RoIs that cover it in registers and
-// stores the result once (no atomics, no zero-fill, summation order = RoI order: bit-
-// reproducible run to run):
-//   roi_rows_kernel      (grid H x N)            per (image, row): the ordered list of RoIs
-//                                                whose patch contains the row
-//   roi_align_bwd_rows   (grid W/XT x H x N)     XT pixels of one row x all channels; RoIs of
-//                                                the row's list are processed four at a time:
-//                                                their separable weights Ay[ph], Bx[pw][x] are
-//                                                built cooperatively in LDS, then each lane
-//                                                (one float4 of channels) streams the
-//                                                contributing gy bins with coalesced reads.
+// stores the result once (no atomics, no zero-fill, summation order = RoI order, then bin
+// order: bit-reproducible run to run):
+//   roi_bwd_tables_kernel  (grid R)    per RoI: its patch extent and the separable weights
+//                                      Ay[y][oh] (already / count) and Bx[ow][x] of every
+//                                      feature row / column, written once to the workspace
+//   roi_align_bwd_owner    (grid = 8-pixel row tiles, XCD-contiguous)
+//                                      one workgroup owns XT = 8 pixels of one row x all
+//                                      channels.  It walks the RoIs in index order, a
+//                                      workgroup-wide chunk at a time:
+//                                       A  ordered compaction of the chunk's RoIs whose patch
+//                                          meets the tile;
+//                                       B  their (RoI, bin) candidates, two per thread, read the
+//                                          tables; the bins with a non-zero weight on the tile
+//                                          are compacted IN ORDER into an LDS list
+//                                          (gy offset, 8 weights ay*bx);
+//                                       C  every lane (one float4 of channels) streams the
+//                                          list four entries at a time — four independent 16 B
+//                                          loads in flight per lane, weights broadcast from LDS,
+//                                          packed fp32 FMAs.
+// The first version of this form rebuilt the weights of four RoIs per barrier pair inside
+// every tile (tap arithmetic with divisions, for all RoIs of the ROW) and issued one
+// dependent gy load per bin: latency-bound at 0.12 of the HBM peak.
 struct RoiExtent { int ylo, yhi, xlo, xhi; };
 
 __device__ __forceinline__ RoiExtent roi_extent(const RoiGeom &g, int H, int W, int PH, int PW)
@@ -322,137 +416,247 @@ __device__ __forceinline__ RoiExtent roi_extent(const RoiGeom &g, int H, int W, 
     return e;
 }
 
-// list[(n*H + y)*R + k] = k-th RoI (ascending index) of image n whose patch contains row y
+constexpr int kOwnXT = 8;        // pixels of a row per workgroup
+constexpr int kOwnThreads = 256; // upper bound of the workgroup size (LDS list capacities)
+constexpr int kOwnScan = 4;      // RoIs tested per thread and chunk
+#ifndef MRCNN_ROI_DEPTH
+#define MRCNN_ROI_DEPTH 4    // measured: 4 at five waves per SIMD = 8 at four; 16 spills
+#endif
+constexpr int kOwnDepth = MRCNN_ROI_DEPTH;     // gy loads in flight per lane
+
+// ext[r] = (ylo | yhi << 16, xlo | xhi << 16, batch, 0);  Ay[r][y][oh];  Bx[r][ow][x] (row
+// stride Wp, a multiple of 8, zero beyond the patch)
 __global__ void __launch_bounds__(256)
-roi_rows_kernel(const float *__restrict__ rois, int R, int H, int W, int PH, int PW,
-                float spatial_scale, int sampling_ratio, uint16_t *__restrict__ lists,
-                int32_t *__restrict__ counts)
+roi_bwd_tables_kernel(const float *__restrict__ rois, int H, int W, int Wp, int PH, int PW, int OH,
+                      int OW, int BS, float spatial_scale, int sampling_ratio,
+                      int4 *__restrict__ ext, float *__restrict__ Ay, float *__restrict__ Bx)
 {
-    __shared__ int wave_cnt[4];
-    const int y = blockIdx.x, n = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint16_t *__restrict__ list = lists + ((int64_t)n * H + y) * R;
-    int base = 0;
-    for (int r0 = 0; r0 < R; r0 += 256) {
-        const int r = r0 + tid;
-        bool in = false;
-        if (r < R) {
-            const RoiGeom g = roi_geom(rois + 5 * r, spatial_scale, PH, PW, sampling_ratio);
-            if (g.batch == n) {
-                const RoiExtent e = roi_extent(g, H, W, PH, PW);
-                in = y >= e.ylo && y <= e.yhi;
+    const int r = blockIdx.x;
+    const RoiGeom g = roi_geom(rois + 5 * r, spatial_scale, PH, PW, sampling_ratio);
+    const RoiExtent e = roi_extent(g, H, W, PH, PW);
+    if (threadIdx.x == 0)
+        ext[r] = make_int4((int)((unsigned)e.ylo | ((unsigned)e.yhi << 16)),
+                           (int)((unsigned)e.xlo | ((unsigned)e.xhi << 16)), g.batch, 0);
+    float *__restrict__ ay = Ay + (int64_t)r * H * OH;
+    for (int i = threadIdx.x; i < H * OH; i += blockDim.x) {
+        const int y = i / OH, oh = i - y * OH;
+        float a = 0.f;
+        if (y >= e.ylo && y <= e.yhi) {
+            const int ph = oh * BS;
+            for (int iy = 0; iy < g.grid_h; ++iy) {
+                const float yy = g.start_h + ph * g.bin_h +
+                                 (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
+                const Tap1D t = tap1d(yy, H);
+                if (!t.valid) continue;
+                if (t.lo == y) a += t.h;
+                if (t.hi == y) a += t.l;
+            }
+            a = a / g.count;
+        }
+        ay[i] = a;
+    }
+    float *__restrict__ bx = Bx + (int64_t)r * OW * Wp;
+    for (int i = threadIdx.x; i < OW * Wp; i += blockDim.x) {
+        const int ow_ = i / Wp, x = i - ow_ * Wp;
+        float b = 0.f;
+        if (x >= e.xlo && x <= e.xhi) {
+            const int pw = ow_ * BS;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float xx = g.start_w + pw * g.bin_w +
+                                 (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
+                const Tap1D t = tap1d(xx, W);
+                if (!t.valid) continue;
+                if (t.lo == x) b += t.h;
+                if (t.hi == x) b += t.l;
             }
         }
-        const unsigned long long b = __ballot(in);
-        if (lane == 0) wave_cnt[wave] = (int)__popcll(b);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (in) list[off + (int)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)r;
-        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+        bx[i] = b;
     }
-    if (tid == 0) counts[n * H + y] = base;
 }
 
-constexpr int kRowsXT = 8;      // pixels of a row per workgroup
-constexpr int kRowsGroup = 4;   // RoIs whose weights are built per barrier pair
-constexpr int kRowsMaxBins = 16;
-
-template <typename V>
-__global__ void __launch_bounds__(256)
-roi_align_bwd_rows_kernel(const V *__restrict__ gy, const float *__restrict__ rois,
-                          const uint16_t *__restrict__ lists, const int32_t *__restrict__ counts,
-                          V *__restrict__ gx, int R, int H, int W, int CV, int PH, int PW,
-                          float spatial_scale, int sampling_ratio, int OH, int OW, int BS)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fma_vec(float acc, float w, float v) { return __builtin_fmaf(w, v, acc); }
+__device__ __forceinline__ float4 fma_vec(float4 acc, float w, float4 v)
 {
-    constexpr int XT = kRowsXT, GR = kRowsGroup, MB = kRowsMaxBins;
-    __shared__ __attribute__((aligned(16))) float sBx[GR][MB][XT];   // [roi][pw][x]
-    __shared__ float sAy[GR][MB];                                     // already / count
-    __shared__ int sRoi[GR];                                          // RoI index or -1 (skip)
-    const int x0 = blockIdx.x * XT, y = blockIdx.y, n = blockIdx.z;
-    const int tid = threadIdx.x;
-    const int cnt = counts[n * H + y];
-    const uint16_t *__restrict__ list = lists + ((int64_t)n * H + y) * R;
-    const int per_roi = OH + OW * XT;            // weight entries of one RoI
-    const int nthreads = blockDim.x;
+    // two v_pk_fma_f32
+    const f32x2 ww = {w, w};
+    const f32x2 lo = __builtin_elementwise_fma((f32x2){v.x, v.y}, ww, (f32x2){acc.x, acc.y});
+    const f32x2 hi = __builtin_elementwise_fma((f32x2){v.z, v.w}, ww, (f32x2){acc.z, acc.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
 
-    for (int c0 = 0; c0 < CV; c0 += nthreads) {
+// acc[x] += w[x] * v for the tile's 8 pixels.  Pixels the bin does not touch carry w = 0 and take
+// the FMA as well (adds 0 for finite gy): per-pixel tests cost four selects per FMA pair here
+// and made this loop, not the loads, the bound of the kernel.
+template <typename V>
+__device__ __forceinline__ void owner_consume(V (&acc)[kOwnXT], const V v, const float *w)
+{
+    const float4 w0 = *reinterpret_cast<const float4 *>(w);
+    const float4 w1 = *reinterpret_cast<const float4 *>(w + 4);
+    const float ww[kOwnXT] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int x = 0; x < kOwnXT; ++x) acc[x] = fma_vec(acc[x], ww[x], v);
+}
+
+#ifndef MRCNN_ROI_WAVES
+#define MRCNN_ROI_WAVES 5
+#endif
+template <typename V>
+__global__ void __launch_bounds__(kOwnThreads) __attribute__((amdgpu_waves_per_eu(MRCNN_ROI_WAVES, 8)))
+roi_align_bwd_owner_kernel(const V *__restrict__ gy, const int4 *__restrict__ ext,
+                           const float *__restrict__ Ay, const float *__restrict__ Bx,
+                           V *__restrict__ gx, int R, int N, int H, int W, int Wp, int CV, int OH,
+                           int OW)
+{
+    constexpr int XT = kOwnXT, CAP = 2 * kOwnThreads;
+    __shared__ int sList[kOwnScan * kOwnThreads];
+    __shared__ int sWave[kOwnThreads / 64];
+    __shared__ int64_t sOff[CAP];        // gy element offset of the bin's first channel vector
+    __shared__ __attribute__((aligned(16))) float sW[CAP][XT];
+
+    // tile id: an XCD (workgroup id mod 8) owns a contiguous run of (image, row, tile) ids, so
+    // the rows that re-read a RoI's gy bins share one L2
+    const int tiles_x = (W + XT - 1) / XT;
+    const int total = tiles_x * H * N;
+    const int per = (total + 7) / 8;
+    const int logical = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if (logical >= total) return;
+    const int x0 = (logical % tiles_x) * XT;
+    const int y = (logical / tiles_x) % H;
+    const int n = logical / (tiles_x * H);
+
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+    const int nb = OH * OW;
+    const int cap = 2 * nthr;
+
+    for (int c0 = 0; c0 < CV; c0 += nthr) {
         const int c = c0 + tid;
+        const bool cok = c < CV;
+        const V *__restrict__ top = gy + (cok ? c : 0);
         V acc[XT];
 #pragma unroll
         for (int x = 0; x < XT; ++x) acc[x] = VecOps<V>::zero();
 
-        for (int k0 = 0; k0 < cnt; k0 += GR) {
-            __syncthreads();                     // the previous group's weights are consumed
-            for (int e = tid; e < GR * per_roi; e += nthreads) {
-                const int gi = e / per_roi, j = e - gi * per_roi;
-                const int k = k0 + gi;
-                if (k >= cnt) {
-                    if (j == 0) sRoi[gi] = -1;
-                    continue;
+        for (int r0 = 0; r0 < R; r0 += kOwnScan * nthr) {
+            // A: the chunk's RoIs whose patch meets this tile, in index order (kOwnScan
+            // consecutive RoIs per thread)
+            bool in[kOwnScan];
+            int lcnt = 0;
+#pragma unroll
+            for (int j = 0; j < kOwnScan; ++j) {
+                const int r = r0 + tid * kOwnScan + j;
+                in[j] = false;
+                if (r < R) {
+                    const int4 e = ext[r];
+                    const int ylo = e.x & 0xffff, yhi = (int)((unsigned)e.x >> 16);
+                    const int xlo = e.y & 0xffff, xhi = (int)((unsigned)e.y >> 16);
+                    in[j] = e.z == n && y >= ylo && y <= yhi && xhi >= x0 && xlo <= x0 + XT - 1;
                 }
-                const int r = list[k];
-                const RoiGeom g = roi_geom(rois + 5 * r, spatial_scale, PH, PW, sampling_ratio);
-                if (j == 0) {
-                    const RoiExtent ex = roi_extent(g, H, W, PH, PW);
-                    sRoi[gi] = (ex.xhi < x0 || ex.xlo > x0 + XT - 1) ? -1 : r;
-                }
-                if (j < OH) {
-                    const int ph = j * BS;
-                    float a = 0.f;
-                    for (int iy = 0; iy < g.grid_h; ++iy) {
-                        const float yy = g.start_h + ph * g.bin_h +
-                                         (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
-                        const Tap1D t = tap1d(yy, H);
-                        if (!t.valid) continue;
-                        if (t.lo == y) a += t.h;
-                        if (t.hi == y) a += t.l;
-                    }
-                    sAy[gi][j] = a / g.count;
-                } else {
-                    const int q = j - OH, ow_ = q / XT, xi = q - ow_ * XT;
-                    const int pw = ow_ * BS, x = x0 + xi;
-                    float b = 0.f;
-                    for (int ix = 0; ix < g.grid_w; ++ix) {
-                        const float xx = g.start_w + pw * g.bin_w +
-                                         (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
-                        const Tap1D t = tap1d(xx, W);
-                        if (!t.valid) continue;
-                        if (t.lo == x) b += t.h;
-                        if (t.hi == x) b += t.l;
-                    }
-                    sBx[gi][ow_][xi] = b;
-                }
+                lcnt += in[j] ? 1 : 0;
             }
+            int linc = lcnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(linc, d);
+                if (lane >= d) linc += t;
+            }
+            __syncthreads();          // the previous chunk's list and wave counts are consumed
+            if (lane == 63) sWave[wave] = linc;
             __syncthreads();
-            if (c < CV) {
-                for (int gi = 0; gi < GR; ++gi) {
-                    const int r = sRoi[gi];
-                    if (r < 0) continue;
-                    const V *__restrict__ top = gy + (int64_t)r * OH * OW * CV + c;
-                    for (int oh = 0; oh < OH; ++oh) {
-                        const float ay = sAy[gi][oh];
-                        if (ay == 0.f) continue;
-                        for (int ow_ = 0; ow_ < OW; ++ow_) {
-                            float w[XT];
-                            bool any = false;
+            int off = 0, m = 0;
+            for (int w = 0; w < nwaves; ++w) {
+                const int cw = sWave[w];
+                if (w < wave) off += cw;
+                m += cw;
+            }
+            off += linc - lcnt;
+#pragma unroll
+            for (int j = 0; j < kOwnScan; ++j)
+                if (in[j]) sList[off++] = r0 + tid * kOwnScan + j;
+            __syncthreads();
+
+            for (int w0 = 0; w0 < m * nb; w0 += cap) {
+                // B: two (RoI, bin) candidates per thread, kept in candidate order
+                float wv[2][XT];
+                int64_t of[2];
+                int mk[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ci = w0 + tid * 2 + j;
+                    mk[j] = 0;
+                    of[j] = 0;
+#pragma unroll
+                    for (int x = 0; x < XT; ++x) wv[j][x] = 0.f;
+                    if (ci < m * nb) {
+                        const int gi = ci / nb, b = ci - gi * nb;
+                        const int oh = b / OW, ow_ = b - oh * OW;
+                        const int rr = sList[gi];
+                        const float ay = Ay[((int64_t)rr * H + y) * OH + oh];
+                        const float4 *bp = reinterpret_cast<const float4 *>(
+                            Bx + ((int64_t)rr * OW + ow_) * Wp + x0);
+                        const float4 b0 = bp[0], b1 = bp[1];     // independent of ay: in flight together
+                        if (ay != 0.f) {
+                            const float bb[XT] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                             for (int x = 0; x < XT; ++x) {
-                                w[x] = sBx[gi][ow_][x];
-                                any |= w[x] != 0.f;
+                                wv[j][x] = ay * bb[x];
+                                if (bb[x] != 0.f) mk[j] |= 1 << x;
                             }
-                            if (!any) continue;
-                            const V v = top[(int64_t)(oh * OW + ow_) * CV];
+                            of[j] = ((int64_t)rr * nb + b) * CV;
+                        }
+                    }
+                }
+                const int lc = (mk[0] != 0) + (mk[1] != 0);
+                int inc = lc;
 #pragma unroll
-                            for (int x = 0; x < XT; ++x)
-                                if (w[x] != 0.f) acc[x] = vfma(acc[x], ay * w[x], v);
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(inc, d);
+                    if (lane >= d) inc += t;
+                }
+                __syncthreads();      // the previous window's list has been consumed
+                if (lane == 63) sWave[wave] = inc;
+                __syncthreads();
+                int base = 0, nent = 0;
+                for (int w = 0; w < nwaves; ++w) {
+                    const int cw = sWave[w];
+                    if (w < wave) base += cw;
+                    nent += cw;
+                }
+                int pos = base + inc - lc;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (mk[j]) {
+                        sOff[pos] = of[j];
+                        *reinterpret_cast<float4 *>(&sW[pos][0]) =
+                            make_float4(wv[j][0], wv[j][1], wv[j][2], wv[j][3]);
+                        *reinterpret_cast<float4 *>(&sW[pos][4]) =
+                            make_float4(wv[j][4], wv[j][5], wv[j][6], wv[j][7]);
+                        ++pos;
+                    }
+                }
+                __syncthreads();
+
+                // C: stream the list, kOwnDepth independent loads in flight per lane.  The
+                // compiler fences keep the weight reads of an entry next to its FMAs (hoisted above
+                // the loads they would hold 8 registers per entry in flight and halve the occupancy)
+                if (cok) {
+                    for (int e = 0; e < nent; e += kOwnDepth) {
+                        V v[kOwnDepth];
+#pragma unroll
+                        for (int i = 0; i < kOwnDepth; ++i)
+                            if (e + i < nent) v[i] = top[sOff[e + i]];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < kOwnDepth; ++i) {
+                            if (e + i < nent) owner_consume(acc, v[i], sW[e + i]);
+                            asm volatile("" ::: "memory");
                         }
                     }
                 }
             }
         }
-        if (c < CV) {
+        if (cok) {
             V *__restrict__ row = gx + (((int64_t)n * H + y) * W + x0) * CV + c;
 #pragma unroll
             for (int x = 0; x < XT; ++x)
@@ -496,13 +700,13 @@ extern "C" int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *
                           4.0 * ((double)bins * C + (double)N * H * W * C), s);
     if (C % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0)) {
         const int cv = C / 4;
-        hipLaunchKernelGGL(roi_align_fwd_kernel<float4>, dim3(bins), dim3(pick_threads(cv)), 0, s,
-                           (const float4 *)x, rois, (float4 *)y, H, W, cv, PH, PW, spatial_scale,
-                           sampling_ratio, OH, OW, bin_stride);
+        hipLaunchKernelGGL(roi_align_fwd_kernel<float4>, dim3((R * OH + 7) / 8 * 8),
+                           dim3(pick_threads(cv)), 0, s, (const float4 *)x, rois, (float4 *)y, H, W,
+                           cv, PH, PW, spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH);
     } else {
-        hipLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3(bins), dim3(pick_threads(C)), 0, s, x,
-                           rois, y, H, W, C, PH, PW, spatial_scale, sampling_ratio, OH, OW,
-                           bin_stride);
+        hipLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3((R * OH + 7) / 8 * 8),
+                           dim3(pick_threads(C)), 0, s, x, rois, y, H, W, C, PH, PW, spatial_scale,
+                           sampling_ratio, OH, OW, bin_stride, R * OH);
     }
     return mrcnn::check_launch("roi_align_fwd");
 }
@@ -515,12 +719,31 @@ extern "C" int mrcnn_roi_align_fwd(const float *x, const float *rois, float *y, 
                                   sampling_ratio, stream);
 }
 
-extern "C" int64_t mrcnn_roi_align_bwd_workspace_bytes(int N, int H, int R)
+namespace {
+// workspace sections of the pixel-owner backward, 256-byte aligned
+struct OwnerWs {
+    int64_t ext, ay, bx, total;
+    int Wp;
+};
+inline OwnerWs owner_ws(int H, int W, int R, int OH, int OW)
 {
-    if (N <= 0 || H <= 0 || R < 0) return 0;
-    // per (image, row): RoI list (uint16) + count (int32), 64-byte aligned sections
-    const int64_t lists = (((int64_t)N * H * R * 2 + 63) / 64) * 64;
-    return lists + (int64_t)N * H * 4 + 64;
+    OwnerWs w;
+    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+    w.Wp = (W + kOwnXT - 1) / kOwnXT * kOwnXT;
+    w.ext = 0;
+    w.ay = up((int64_t)R * 16);
+    w.bx = w.ay + up((int64_t)R * H * OH * 4);
+    w.total = w.bx + up((int64_t)R * OW * w.Wp * 4);
+    return w;
+}
+}  // namespace
+
+extern "C" int64_t mrcnn_roi_align_bwd_workspace_bytes(int N, int H, int W, int R, int PH, int PW,
+                                                       int bin_stride)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || R <= 0 || PH <= 0 || PW <= 0 || bin_stride < 1) return 0;
+    const int OH = (PH + bin_stride - 1) / bin_stride, OW = (PW + bin_stride - 1) / bin_stride;
+    return owner_ws(H, W, R, OH, OW).total;
 }
 
 extern "C" int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float *gx, int N, int H,
@@ -535,25 +758,27 @@ extern "C" int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float 
     const int OH = (PH + bin_stride - 1) / bin_stride, OW = (PW + bin_stride - 1) / bin_stride;
     const int bins = R * OH * OW;
     const bool vec = C % 4 == 0 && ((uintptr_t)gx % 16 == 0) && ((uintptr_t)gy % 16 == 0);
-    if (ws && R > 0 && R <= 65535 && H <= 65535 && N <= 65535 && OH <= kRowsMaxBins &&
-        OW <= kRowsMaxBins) {
+    const int64_t tiles = (int64_t)((W + kOwnXT - 1) / kOwnXT) * H * N;
+    if (ws && R > 0 && H <= 65535 && W <= 65535 && tiles + 8 < (int64_t)INT32_MAX &&
+        (uintptr_t)ws % 16 == 0) {
         // pixel-owner form: every gx element is written exactly once, no zero-fill.
         // algorithmic bytes: read R*OH*OW*C, write the feature-map gradient
         mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_BWD, 0.,
                               4.0 * ((double)bins * C + (double)N * H * W * C), s);
-        uint16_t *lists = (uint16_t *)ws;
-        int32_t *counts = (int32_t *)((char *)ws + (((int64_t)N * H * R * 2 + 63) / 64) * 64);
-        hipLaunchKernelGGL(roi_rows_kernel, dim3(H, N), dim3(256), 0, s, rois, R, H, W, PH, PW,
-                           spatial_scale, sampling_ratio, lists, counts);
-        const dim3 grid((W + kRowsXT - 1) / kRowsXT, H, N);
+        const OwnerWs w = owner_ws(H, W, R, OH, OW);
+        int4 *ext = (int4 *)((char *)ws + w.ext);
+        float *Ay = (float *)((char *)ws + w.ay);
+        float *Bx = (float *)((char *)ws + w.bx);
+        hipLaunchKernelGGL(roi_bwd_tables_kernel, dim3(R), dim3(256), 0, s, rois, H, W, w.Wp, PH, PW,
+                           OH, OW, bin_stride, spatial_scale, sampling_ratio, ext, Ay, Bx);
+        const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
         if (vec)
-            hipLaunchKernelGGL(roi_align_bwd_rows_kernel<float4>, grid, dim3(pick_threads(C / 4)), 0,
-                               s, (const float4 *)gy, rois, lists, counts, (float4 *)gx, R, H, W,
-                               C / 4, PH, PW, spatial_scale, sampling_ratio, OH, OW, bin_stride);
+            hipLaunchKernelGGL(roi_align_bwd_owner_kernel<float4>, grid, dim3(pick_threads(C / 4)), 0,
+                               s, (const float4 *)gy, ext, Ay, Bx, (float4 *)gx, R, N, H, W, w.Wp,
+                               C / 4, OH, OW);
         else
-            hipLaunchKernelGGL(roi_align_bwd_rows_kernel<float>, grid, dim3(pick_threads(C)), 0, s,
-                               gy, rois, lists, counts, gx, R, H, W, C, PH, PW, spatial_scale,
-                               sampling_ratio, OH, OW, bin_stride);
+            hipLaunchKernelGGL(roi_align_bwd_owner_kernel<float>, grid, dim3(pick_threads(C)), 0, s,
+                               gy, ext, Ay, Bx, gx, R, N, H, W, w.Wp, C, OH, OW);
         return mrcnn::check_launch("roi_align_bwd");
     }
     MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * H * W * C, s));

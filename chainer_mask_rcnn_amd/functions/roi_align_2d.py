@@ -45,7 +45,8 @@ class _ROIAlign2DFn(torch.autograd.Function):
         gy = nhwc(gy)
         gx = empty_nhwc((N, C, H, W), gy.device)
         R = rois.shape[0]
-        ws = _lib.workspace(_lib.load().mrcnn_roi_align_bwd_workspace_bytes(N, H, R), gy.device,
+        ws = _lib.workspace(_lib.load().mrcnn_roi_align_bwd_workspace_bytes(
+            N, H, W, R, outh, outw, bin_stride), gy.device,
                             'roi_align_bwd') if DETERMINISTIC_BACKWARD else None
         _lib.call('mrcnn_roi_align_bwd_ex', _lib.ptr(gy), _lib.ptr(rois), _lib.ptr(gx),
                   N, H, W, C, R, outh, outw, bin_stride, spatial_scale,

@@ -75,12 +75,14 @@ int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *y,
                            float spatial_scale, int sampling_ratio, void *stream);
 /* Backward, two forms.  ws = NULL (and mrcnn_roi_align_bwd): gather form with one atomic add
  * per (RoI patch pixel, channel) into a zero-filled gx — the order of the fp32 additions, like
- * the reference's atomicAdd kernel (:508-515), varies from run to run.  ws = a workspace of
- * mrcnn_roi_align_bwd_workspace_bytes(N, H, R): pixel-owner form — per (image, row) an ordered
- * RoI list is built, every gx pixel is summed in registers over the RoIs that cover it (in
- * RoI order) and stored once: no atomics, no zero-fill, bit-reproducible, ~4x faster at the
- * C2 shape (R <= 65535 and at most 16 x 16 produced bins; otherwise the first form runs). */
-int64_t mrcnn_roi_align_bwd_workspace_bytes(int N, int H, int R);
+ * the reference's atomicAdd kernel (:508-515), varies from run to run.  ws = a 16-byte aligned
+ * workspace of mrcnn_roi_align_bwd_workspace_bytes(N, H, W, R, PH, PW, bin_stride): pixel-owner
+ * form — per RoI the patch extent and the separable bilinear weights of every feature row and
+ * column are tabulated once, then every gx pixel is summed in registers over the RoIs that cover
+ * it (in RoI order, bins in row-major order) and stored once: no atomics, no zero-fill,
+ * bit-reproducible, ~10x faster at the C2 shape (H, W <= 65535; otherwise the first form runs). */
+int64_t mrcnn_roi_align_bwd_workspace_bytes(int N, int H, int W, int R, int PH, int PW,
+                                            int bin_stride);
 int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float *gx,
                            int N, int H, int W, int C, int R, int PH, int PW, int bin_stride,
                            float spatial_scale, int sampling_ratio, void *ws, void *stream);
