@@ -159,6 +159,61 @@ __device__ __forceinline__ void fwd_bins(const V *__restrict__ img, V *__restric
     }
 }
 
+// One bin with any sampling grid: the 4 * GW taps of one sample row in flight together (GW = 0:
+// run-time grid width, one sample at a time), sample rows in sequence — the reference's order.
+template <typename V, int GW>
+__device__ __forceinline__ void fwd_bin_rows(const V *__restrict__ img, V *__restrict__ out,
+                                             const RoiGeom &g, int ph, int ow_, int BS, int H, int W,
+                                             int CV)
+{
+    const int pw = ow_ * BS;
+    V acc = VecOps<V>::zero();
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+        const float yy = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
+        const Tap1D ty = tap1d(yy, H);
+        if constexpr (GW > 0) {
+            V v[GW][4];
+            float wt[GW][4];
+            bool ok[GW];
+#pragma unroll
+            for (int ix = 0; ix < GW; ++ix) {
+                const float xx = g.start_w + pw * g.bin_w +
+                                 (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
+                const Tap1D tx = tap1d(xx, W);
+                ok[ix] = ty.valid && tx.valid;
+                wt[ix][0] = ty.h * tx.h;
+                wt[ix][1] = ty.h * tx.l;
+                wt[ix][2] = ty.l * tx.h;
+                wt[ix][3] = ty.l * tx.l;
+                v[ix][0] = img[((int64_t)ty.lo * W + tx.lo) * CV];
+                v[ix][1] = img[((int64_t)ty.lo * W + tx.hi) * CV];
+                v[ix][2] = img[((int64_t)ty.hi * W + tx.lo) * CV];
+                v[ix][3] = img[((int64_t)ty.hi * W + tx.hi) * CV];
+            }
+#pragma unroll
+            for (int ix = 0; ix < GW; ++ix)
+                if (ok[ix])
+                    acc = VecOps<V>::mad4(acc, wt[ix][0], v[ix][0], wt[ix][1], v[ix][1], wt[ix][2],
+                                          v[ix][2], wt[ix][3], v[ix][3]);
+        } else {
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float xx = g.start_w + pw * g.bin_w +
+                                 (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
+                const Tap1D tx = tap1d(xx, W);
+                if (!(ty.valid && tx.valid)) continue;
+                const float w1 = ty.h * tx.h, w2 = ty.h * tx.l;
+                const float w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+                const V v1 = img[((int64_t)ty.lo * W + tx.lo) * CV];
+                const V v2 = img[((int64_t)ty.lo * W + tx.hi) * CV];
+                const V v3 = img[((int64_t)ty.hi * W + tx.lo) * CV];
+                const V v4 = img[((int64_t)ty.hi * W + tx.hi) * CV];
+                acc = VecOps<V>::mad4(acc, w1, v1, w2, v2, w3, v3, w4, v4);
+            }
+        }
+    }
+    store_stream(&out[(int64_t)ow_ * CV], VecOps<V>::div(acc, g.count));
+}
+
 // V = float4 when C % 4 == 0 (CV = C/4 vectors per pixel), else float.
 // One workgroup owns one output ROW of a RoI (OW bins): a workgroup per bin (the first version)
 // lived for one RoI read + four dependent-latency loads + one store and was bound by that
@@ -192,30 +247,16 @@ roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois, V 
             for (int ow0 = 0; ow0 < OW; ow0 += 2) fwd_bins<V, 2, 1, 2>(img, out, g, ph, ow0, OW, BS, H, W, CV);
         } else if (g.grid_h == 2 && g.grid_w == 2) {
             for (int ow0 = 0; ow0 < OW; ++ow0) fwd_bins<V, 2, 2, 1>(img, out, g, ph, ow0, OW, BS, H, W, CV);
+        } else if (g.grid_w == 1) {
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 1>(img, out, g, ph, ow_, BS, H, W, CV);
+        } else if (g.grid_w == 2) {
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 2>(img, out, g, ph, ow_, BS, H, W, CV);
+        } else if (g.grid_w == 3) {
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 3>(img, out, g, ph, ow_, BS, H, W, CV);
+        } else if (g.grid_w == 4) {
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 4>(img, out, g, ph, ow_, BS, H, W, CV);
         } else {
-            for (int ow_ = 0; ow_ < OW; ++ow_) {
-                const int pw = ow_ * BS;
-                V acc = VecOps<V>::zero();
-                for (int iy = 0; iy < g.grid_h; ++iy) {
-                    const float yy = g.start_h + ph * g.bin_h +
-                                     (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
-                    const Tap1D ty = tap1d(yy, H);
-                    for (int ix = 0; ix < g.grid_w; ++ix) {
-                        const float xx = g.start_w + pw * g.bin_w +
-                                         (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
-                        const Tap1D tx = tap1d(xx, W);
-                        if (!(ty.valid && tx.valid)) continue;
-                        const float w1 = ty.h * tx.h, w2 = ty.h * tx.l;
-                        const float w3 = ty.l * tx.h, w4 = ty.l * tx.l;
-                        const V v1 = img[((int64_t)ty.lo * W + tx.lo) * CV];
-                        const V v2 = img[((int64_t)ty.lo * W + tx.hi) * CV];
-                        const V v3 = img[((int64_t)ty.hi * W + tx.lo) * CV];
-                        const V v4 = img[((int64_t)ty.hi * W + tx.hi) * CV];
-                        acc = VecOps<V>::mad4(acc, w1, v1, w2, v2, w3, v3, w4, v4);
-                    }
-                }
-                store_stream(&out[(int64_t)ow_ * CV], VecOps<V>::div(acc, g.count));
-            }
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 0>(img, out, g, ph, ow_, BS, H, W, CV);
         }
     }
 }

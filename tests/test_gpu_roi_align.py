@@ -57,6 +57,39 @@ def test_forward_bit_exact_vs_oracle(dev, C, sr):
     np.testing.assert_allclose(gx, gx_ref, rtol=RTOL, atol=1e-4)
 
 
+@pytest.mark.parametrize('outhw', [(7, 7), (3, 5), (2, 9)])
+def test_forward_every_sampling_grid_path_bit_exact(dev, outhw):
+    """The forward kernel picks an unrolled body per sampling grid of the RoI ((1,1), (1,2),
+    (2,1), (2,2): all taps of 4 / 2 / 2 / 1 bins in flight) and a generic loop otherwise.  RoIs
+    built to land on every grid (gh, gw) in {1,2,3}^2 under adaptive sampling, partly outside
+    the map (samples the reference skips), output widths that leave a partial last bin group."""
+    outh, outw = outhw
+    rng = np.random.RandomState(outh * 16 + outw)
+    N, C, H, W = 2, 12, 30, 41
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = []
+    for gh in (1, 2, 3):
+        for gw in (1, 2, 3):
+            for k in range(4):
+                h = (gh - 0.5) * outh * 16.0 + rng.uniform(-3, 3)     # ceil(h / 16 / outh) == gh
+                w = (gw - 0.5) * outw * 16.0 + rng.uniform(-3, 3)
+                y1 = rng.uniform(-40, H * 16 - 0.5 * h)
+                x1 = rng.uniform(-40, W * 16 - 0.5 * w)
+                rois.append([rng.randint(0, N), x1, y1, x1 + w, y1 + h])
+    rois = np.asarray(rois, np.float32)
+    rh = np.maximum((rois[:, 4] - rois[:, 2]) / 16., 1.)
+    rw = np.maximum((rois[:, 3] - rois[:, 1]) / 16., 1.)
+    grids = set(zip(np.ceil(rh / outh).astype(int).tolist(), np.ceil(rw / outw).astype(int).tolist()))
+    assert grids >= {(a, b) for a in (1, 2, 3) for b in (1, 2, 3)}
+    y = F.roi_align_2d(torch.tensor(x, device=dev), torch.tensor(rois, device=dev), outh, outw,
+                       1 / 16., 0).cpu().numpy()
+    assert np.array_equal(y, oracle.roi_align_fwd(x, rois, outh, outw, 1 / 16., 0))
+    for sr in (1, 2, 3):
+        y = F.roi_align_2d(torch.tensor(x, device=dev), torch.tensor(rois, device=dev), outh, outw,
+                           1 / 16., sr).cpu().numpy()
+        assert np.array_equal(y, oracle.roi_align_fwd(x, rois, outh, outw, 1 / 16., sr))
+
+
 def test_out_of_range_samples_skipped(dev):
     x = np.ones((1, 4, 4, 4), np.float32)
     rois = np.array([[0, 0, 0, 200, 200], [0, -50, -50, 2, 2]], np.float32)

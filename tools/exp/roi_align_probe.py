@@ -58,7 +58,12 @@ def main():
     yc = (rois[:, 2] + rois[:, 4]) * 0.5 * scale
     xc = (rois[:, 1] + rois[:, 3]) * 0.5 * scale
     order = np.lexsort((xc, (yc // 6).astype(int), rois[:, 0]))
-    for tag, rr in (('as sampled', rois), ('spatially sorted', rois[order])):
+    rb = np.random.RandomState(5)
+    big = rois.copy()
+    hh, ww = rb.uniform(32, 600, len(big)), rb.uniform(32, 600, len(big))
+    big[:, 2] = rb.uniform(0, 800 - 32, len(big)); big[:, 1] = rb.uniform(0, 1333 - 32, len(big))
+    big[:, 4] = np.minimum(big[:, 2] + hh, 800); big[:, 3] = np.minimum(big[:, 1] + ww, 1333)
+    for tag, rr in (('as sampled', rois), ('spatially sorted', rois[order]), ('object-sized (32..600 px)', big)):
         rd = torch.tensor(np.ascontiguousarray(rr), device=dev)
         for name in ('fwd', 'bwd'):
             ts = []
