@@ -224,7 +224,7 @@ template <typename V>
 __global__ void __launch_bounds__(256)
 roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois, V *__restrict__ y,
                      int H, int W, int CV, int PH, int PW, float spatial_scale, int sampling_ratio,
-                     int OH, int OW, int BS, int rows)
+                     int OH, int OW, int BS, int rows, const int *__restrict__ order)
 {
     // output bin (oh, ow) is bin (oh*BS, ow*BS) of the PH x PW grid (BS = 1: every bin)
     // an XCD (workgroup id mod 8) owns a contiguous run of rows (n*OH + oh): the OH rows of a
@@ -232,13 +232,17 @@ roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois, V 
     const int per = ((int)gridDim.x + 7) / 8;
     const int row = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
     if (row >= rows) return;
-    const int ph = (row % OH) * BS;
-    const int n = row / OH;
+    // `order` (optional): the RoI processed at position row / OH — a permutation that puts
+    // neighbouring RoIs next to each other, so that an XCD's run of rows covers one region of
+    // the map; results do not depend on it
+    const int oh = row % OH;
+    const int ph = oh * BS;
+    const int n = order ? order[row / OH] : row / OH;
     const RoiGeom g = roi_geom(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio);
 
     for (int c = threadIdx.x; c < CV; c += blockDim.x) {
         const V *__restrict__ img = x + (int64_t)g.batch * H * W * CV + c;
-        V *__restrict__ out = y + (int64_t)row * OW * CV + c;
+        V *__restrict__ out = y + ((int64_t)n * OH + oh) * OW * CV + c;
         if (g.grid_h == 1 && g.grid_w == 1) {
             for (int ow0 = 0; ow0 < OW; ow0 += 4) fwd_bins<V, 1, 1, 4>(img, out, g, ph, ow0, OW, BS, H, W, CV);
         } else if (g.grid_h == 1 && g.grid_w == 2) {
@@ -728,7 +732,8 @@ int check_args(const void *a, const void *b, const void *c, int N, int H, int W,
 
 extern "C" int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *y, int N, int H,
                                       int W, int C, int R, int PH, int PW, int bin_stride,
-                                      float spatial_scale, int sampling_ratio, void *stream)
+                                      float spatial_scale, int sampling_ratio, const int *order,
+                                      void *stream)
 {
     if (int rc = check_args(x, rois, y, N, H, W, C, R, PH, PW, sampling_ratio)) return rc;
     MRCNN_REQUIRE(bin_stride >= 1, "roi_align: bin_stride must be >= 1");
@@ -743,11 +748,11 @@ extern "C" int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *
         const int cv = C / 4;
         hipLaunchKernelGGL(roi_align_fwd_kernel<float4>, dim3((R * OH + 7) / 8 * 8),
                            dim3(pick_threads(cv)), 0, s, (const float4 *)x, rois, (float4 *)y, H, W,
-                           cv, PH, PW, spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH);
+                           cv, PH, PW, spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH, order);
     } else {
         hipLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3((R * OH + 7) / 8 * 8),
                            dim3(pick_threads(C)), 0, s, x, rois, y, H, W, C, PH, PW, spatial_scale,
-                           sampling_ratio, OH, OW, bin_stride, R * OH);
+                           sampling_ratio, OH, OW, bin_stride, R * OH, order);
     }
     return mrcnn::check_launch("roi_align_fwd");
 }
@@ -757,7 +762,7 @@ extern "C" int mrcnn_roi_align_fwd(const float *x, const float *rois, float *y, 
                                    int sampling_ratio, void *stream)
 {
     return mrcnn_roi_align_fwd_ex(x, rois, y, N, H, W, C, R, PH, PW, 1, spatial_scale,
-                                  sampling_ratio, stream);
+                                  sampling_ratio, nullptr, stream);
 }
 
 namespace {

@@ -6,6 +6,7 @@ from .affine_channel_2d import AffineChannel2DFunction
 
 from .roi_align_2d import roi_align_2d
 from .roi_align_2d import ROIAlign2D
+from .roi_align_2d import spatial_order as roi_spatial_order
 
 from .conv import conv2d, deconv2x2s2, linear, stem_conv, bottleneck, building_block
 from .pooling import max_pooling_2d, average_pooling_2d

@@ -19,7 +19,7 @@ DETERMINISTIC_BACKWARD = True
 class _ROIAlign2DFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, rois, outh, outw, spatial_scale, sampling_ratio, bin_stride=1):
+    def forward(ctx, x, rois, outh, outw, spatial_scale, sampling_ratio, bin_stride=1, order=None):
         _lib.require_device(x, rois)
         x = nhwc(x)
         rois = rois.contiguous()
@@ -28,9 +28,14 @@ class _ROIAlign2DFn(torch.autograd.Function):
         oh = (outh + bin_stride - 1) // bin_stride
         ow = (outw + bin_stride - 1) // bin_stride
         y = empty_nhwc((R, C, oh, ow), x.device)
+        if order is not None:
+            if not (order.dtype == torch.int32 and order.is_contiguous() and order.device == x.device
+                    and tuple(order.shape) == (R,)):
+                raise TypeError('roi_align_2d: order must be a contiguous int32 device tensor of '
+                                'shape (R,) — a permutation of the RoI rows')
         _lib.call('mrcnn_roi_align_fwd_ex', _lib.ptr(x), _lib.ptr(rois), _lib.ptr(y),
                   N, H, W, C, R, outh, outw, bin_stride, spatial_scale, sampling_ratio,
-                  _lib.stream_ptr())
+                  _lib.ptr(order) if order is not None and R > 0 else None, _lib.stream_ptr())
         # only rois are retained (roi_align_2d.py:62-63 retain_inputs((1,)))
         ctx.save_for_backward(rois)
         ctx.x_shape = (N, C, H, W)
@@ -52,15 +57,16 @@ class _ROIAlign2DFn(torch.autograd.Function):
                   N, H, W, C, R, outh, outw, bin_stride, spatial_scale,
                   sampling_ratio, _lib.ptr(ws), _lib.stream_ptr())
         # no gradient w.r.t. rois (roi_align_2d.py:389, :524)
-        return gx, None, None, None, None, None, None
+        return gx, None, None, None, None, None, None, None
 
 
 class ROIAlign2D(object):
 
     """ROI align over a set of 2d planes (reference: roi_align_2d.py:25-47)."""
 
-    def __init__(self, outh, outw, spatial_scale, sampling_ratio=0, bin_stride=1):
+    def __init__(self, outh, outw, spatial_scale, sampling_ratio=0, bin_stride=1, order=None):
         self.bin_stride = int(bin_stride)
+        self.order = order
         for arg, value in (('outh', outh), ('outw', outw),
                            ('sampling_ratio', sampling_ratio)):
             if not (isinstance(value, int) and not isinstance(value, bool)
@@ -90,11 +96,23 @@ class ROIAlign2D(object):
     def __call__(self, x, rois):
         self.check_type_forward(x, rois)
         return _ROIAlign2DFn.apply(x, rois, self.outh, self.outw,
-                                   self.spatial_scale, self.sampling_ratio, self.bin_stride)
+                                   self.spatial_scale, self.sampling_ratio, self.bin_stride,
+                                   self.order)
+
+
+def spatial_order(rois_yx, roi_indices, spatial_scale, band=6.0):
+    """Processing order for ``roi_align_2d(..., order=)`` from HOST arrays: RoIs sorted by
+    (image, band of ``band`` feature rows of the box centre, x centre).  ``rois_yx`` (R, 4) rows
+    ``(y_min, x_min, y_max, x_max)``, ``roi_indices`` (R,).  Returns int32 (R,) NumPy."""
+    import numpy as np
+    rois_yx = np.asarray(rois_yx, np.float32).reshape(-1, 4)
+    yc = (rois_yx[:, 0] + rois_yx[:, 2]) * (0.5 * spatial_scale)
+    xc = (rois_yx[:, 1] + rois_yx[:, 3]) * (0.5 * spatial_scale)
+    return np.lexsort((xc, np.floor(yc / band), np.asarray(roi_indices))).astype(np.int32)
 
 
 def roi_align_2d(x, rois, outh, outw, spatial_scale, sampling_ratio=0, axes='xy',
-                 bin_stride=1):
+                 bin_stride=1, order=None):
     """Spatial Region of Interest (ROI) align function.
 
     x: (N, C, H, W) float32; rois: (R, 5) float32 rows
@@ -104,9 +122,12 @@ def roi_align_2d(x, rois, outh, outw, spatial_scale, sampling_ratio=0, axes='xy'
 
     ``bin_stride`` (extension, default 1 = reference behaviour): produce only every
     ``bin_stride``-th bin in each direction, i.e. exactly ``roi_align_2d(...)[:, :, ::s, ::s]``.
+
+    ``order`` (extension, default None): int32 device permutation of the RoI rows — the sequence
+    in which the forward kernel PROCESSES them (``spatial_order``); the result does not depend on it.
     """
     if axes not in ['xy', 'yx']:
         raise ValueError('Unsupported axes: {}'.format(axes))
     if axes == 'yx':
         rois = rois[:, [0, 2, 1, 4, 3]]
-    return ROIAlign2D(outh, outw, spatial_scale, sampling_ratio, bin_stride)(x, rois)
+    return ROIAlign2D(outh, outw, spatial_scale, sampling_ratio, bin_stride, order)(x, rois)

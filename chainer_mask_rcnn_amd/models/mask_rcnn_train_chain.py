@@ -238,10 +238,17 @@ class MaskRCNNTrainChain(torch.nn.Module):
         # row -> position among the foreground rows (-1: background), for the fused res5 tail
         fg_slot = np.full((len(gt_roi_labels_h),), -1, np.int32)
         fg_slot[fg_rows.astype(np.int64)] = np.arange(len(fg_rows), dtype=np.int32)
-        sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels, fg_rows_d, fg_slot_d = _upload_many(
-            [cat(sample_rois), cat(sample_roi_indices), cat(gt_roi_locs), gt_roi_labels_h, fg_rows, fg_slot],
-            [torch.float32, torch.int32, torch.float32, torch.int32, torch.int64, torch.int32], dev)
+        # processing order of the RoIs for the ROIAlign forward (same values in any order)
+        from ..functions.roi_align_2d import spatial_order
+        roi_order = spatial_order(cat(sample_rois), cat(sample_roi_indices), self.mask_rcnn.head.spatial_scale)
+        (sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels, fg_rows_d, fg_slot_d,
+         roi_order_d) = _upload_many(
+            [cat(sample_rois), cat(sample_roi_indices), cat(gt_roi_locs), gt_roi_labels_h, fg_rows, fg_slot,
+             roi_order],
+            [torch.float32, torch.int32, torch.float32, torch.int32, torch.int64, torch.int32,
+             torch.int32], dev)
         fg_rows_d._mrcnn_slot = fg_slot_d
+        sample_rois._mrcnn_order = roi_order_d
 
         # The reference runs the mask branch on every sampled RoI (:147-148) although
         # background rows carry all-ignored (-1) mask targets and therefore contribute

@@ -123,3 +123,21 @@ def test_kernel_selection_switches_without_device(lib):
     assert conv.GEMM_ARITHMETIC == 'split_bf16x3'
     conv.set_gemm_arithmetic('fp32')
     assert conv.GEMM_ARITHMETIC == 'fp32'
+
+
+def test_roi_spatial_order_is_a_permutation_grouped_by_image_and_band():
+    """Host helper behind roi_align_2d(order=): sorted by (image, 6-row band of the centre, x centre)."""
+    import numpy as np
+    from chainer_mask_rcnn_amd import functions
+    rng = np.random.RandomState(0)
+    R = 200
+    y1 = rng.uniform(0, 700, R); x1 = rng.uniform(0, 1200, R)
+    rois = np.stack([y1, x1, y1 + rng.uniform(8, 300, R), x1 + rng.uniform(8, 300, R)], 1).astype(np.float32)
+    idx = rng.randint(0, 2, R)
+    o = functions.roi_spatial_order(rois, idx, 1 / 16.)
+    assert o.dtype == np.int32 and sorted(o.tolist()) == list(range(R))
+    yc = (rois[:, 0] + rois[:, 2]) * (0.5 / 16.)
+    xc = (rois[:, 1] + rois[:, 3]) * (0.5 / 16.)
+    keys = [(int(idx[i]), int(np.floor(yc[i] / 6.0)), float(xc[i])) for i in o]
+    assert keys == sorted(keys)
+    assert functions.roi_spatial_order(np.zeros((0, 4), np.float32), np.zeros((0,), np.int32), 1 / 16.).shape == (0,)

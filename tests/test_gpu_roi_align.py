@@ -90,6 +90,35 @@ def test_forward_every_sampling_grid_path_bit_exact(dev, outhw):
         assert np.array_equal(y, oracle.roi_align_fwd(x, rois, outh, outw, 1 / 16., sr))
 
 
+def test_processing_order_does_not_change_the_result(dev):
+    """roi_align_2d(order=...) only changes which workgroup handles which RoI: forward output and
+    gradient are bit-identical for the identity, a random and the spatially sorted order."""
+    rng = np.random.RandomState(7)
+    N, C, H, W, R = 2, 24, 25, 38, 70
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    y1 = rng.uniform(0, H * 16, R); x1 = rng.uniform(0, W * 16, R)
+    y2 = np.minimum(y1 + rng.uniform(0, 300, R), H * 16); x2 = np.minimum(x1 + rng.uniform(0, 400, R), W * 16)
+    idx = rng.randint(0, N, R)
+    rois = np.stack([idx, y1, x1, y2, x2], 1).astype(np.float32)
+    gy = torch.tensor(rng.standard_normal((R, C, 7, 7)).astype(np.float32), device=dev)
+    orders = [None, rng.permutation(R).astype(np.int32),
+              F.roi_spatial_order(rois[:, 1:], idx, 1 / 16.)]
+    assert sorted(orders[2].tolist()) == list(range(R))
+    outs = []
+    for o in orders:
+        xt = torch.tensor(x, device=dev, requires_grad=True)
+        od = None if o is None else torch.tensor(o, device=dev)
+        y = F.roi_align_2d(xt, torch.tensor(rois, device=dev), 14, 14, 1 / 16., axes='yx',
+                           bin_stride=2, order=od)
+        y.backward(gy)
+        outs.append((y.detach().clone(), xt.grad.clone()))
+    for y, g in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(g, outs[0][1])
+    with pytest.raises(TypeError):
+        F.roi_align_2d(torch.tensor(x, device=dev), torch.tensor(rois, device=dev), 14, 14, 1 / 16.,
+                       axes='yx', order=torch.zeros(R, dtype=torch.int64, device=dev))
+
+
 def test_out_of_range_samples_skipped(dev):
     x = np.ones((1, 4, 4, 4), np.float32)
     rois = np.array([[0, 0, 0, 200, 200], [0, -50, -50, 2, 2]], np.float32)

@@ -31,7 +31,7 @@ def main():
     torch.cuda.synchronize()
     ra._ROIAlign2DFn.forward = staticmethod(orig)
     shape, rois, a = seen[-1]
-    outh, outw, scale, sr, bs = a
+    outh, outw, scale, sr, bs = a[:5]
     N, C, H, W = shape
     print('x', shape, 'rois', rois.shape, 'args', a)
     rw = np.maximum((rois[:, 3] - rois[:, 1]) * scale, 1.0)
@@ -63,18 +63,24 @@ def main():
     hh, ww = rb.uniform(32, 600, len(big)), rb.uniform(32, 600, len(big))
     big[:, 2] = rb.uniform(0, 800 - 32, len(big)); big[:, 1] = rb.uniform(0, 1333 - 32, len(big))
     big[:, 4] = np.minimum(big[:, 2] + hh, 800); big[:, 3] = np.minimum(big[:, 1] + ww, 1333)
-    for tag, rr in (('as sampled', rois), ('spatially sorted', rois[order]), ('object-sized (32..600 px)', big)):
+    so = ra.spatial_order(rois[:, [2, 1, 4, 3]], rois[:, 0], scale)
+    sob = ra.spatial_order(big[:, [2, 1, 4, 3]], big[:, 0], scale)
+    for tag, rr, oo in (('as sampled', rois, None), ('as sampled, order=spatial_order', rois, so),
+                        ('host-sorted rows', rois[order], None),
+                        ('object-sized (32..600 px)', big, None),
+                        ('object-sized, order=spatial_order', big, sob)):
         rd = torch.tensor(np.ascontiguousarray(rr), device=dev)
+        od = None if oo is None else torch.tensor(oo, device=dev)
         for name in ('fwd', 'bwd'):
             ts = []
             for it in range(25):
-                y = ra._ROIAlign2DFn.apply(x, rd, outh, outw, scale, sr, bs)
+                y = ra._ROIAlign2DFn.apply(x, rd, outh, outw, scale, sr, bs, od)
                 gy = torch.randn_like(y)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda._sleep(400000)      # keep the queue busy while the host enqueues
                 if name == 'fwd':
-                    e0.record(); y = ra._ROIAlign2DFn.apply(x, rd, outh, outw, scale, sr, bs); e1.record()
+                    e0.record(); y = ra._ROIAlign2DFn.apply(x, rd, outh, outw, scale, sr, bs, od); e1.record()
                 else:
                     e0.record(); y.backward(gy); e1.record()
                 torch.cuda.synchronize()
