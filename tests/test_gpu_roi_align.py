@@ -156,6 +156,38 @@ def test_gradient_mass_full_size_property(dev):
     assert abs(s_gx - s_gy) <= 1e-4 * gy.double().abs().sum().item()
 
 
+def test_backward_forms_agree_at_full_c2_size(dev):
+    """BASELINE configs[1] shape (2 x 1024 x 51 x 84, 1024 RoIs, 14x14 bins read with stride 2):
+    the pixel-owner backward (tables + ordered entry lists) against the atomic gather form, on
+    benchmark-like small RoIs and on object-sized ones; gradient mass preserved."""
+    import importlib
+    mod = importlib.import_module('chainer_mask_rcnn_amd.functions.roi_align_2d')
+    N, C, H, W, R = 2, 1024, 51, 84, 1024
+    g = torch.Generator(device='cpu').manual_seed(3)
+    for lo, hi in ((30., 200.), (32., 600.)):
+        yx = torch.rand((R, 2), generator=g) * torch.tensor([760., 1290.])
+        hw = torch.rand((R, 2), generator=g) * (hi - lo) + lo
+        br = torch.minimum(yx + hw, torch.tensor([800., 1333.]))
+        rois = torch.cat([torch.randint(0, N, (R, 1), generator=g).float(), yx, br], 1).to(dev)
+        gy = torch.randn((R, 7, 7, C), generator=g).to(dev).permute(0, 3, 1, 2)
+        grads = []
+        for det in (True, False):
+            old = mod.DETERMINISTIC_BACKWARD
+            mod.DETERMINISTIC_BACKWARD = det
+            try:
+                x = torch.zeros((N, C, H, W), device=dev).contiguous(memory_format=torch.channels_last)
+                x.requires_grad_(True)
+                F.roi_align_2d(x, rois, 14, 14, 1 / 16., axes='yx', bin_stride=2).backward(gy)
+                grads.append(x.grad.clone())
+            finally:
+                mod.DETERMINISTIC_BACKWARD = old
+        a, b = grads
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale
+        s_gx, s_gy = a.double().sum().item(), gy.double().sum().item()
+        assert abs(s_gx - s_gy) <= 1e-4 * gy.double().abs().sum().item()
+
+
 @pytest.mark.parametrize('C', [8, 64])
 def test_bin_stride_equals_subsampled_full(dev, C):
     """bin_stride=2 == the even bins of the full 14x14 ROIAlign, forward (bit-exact) and
