@@ -164,6 +164,41 @@ def profile_summary():
     return out
 
 
+def roi_align_isolated(chain, device, reps=20):
+    """ROIAlign forward / backward ALONE on the GPU on the RoIs the last timed step sampled (same
+    shapes, bin stride and processing order as the model's call), timed by the in-library HIP
+    events.  Inside the step the two kernels run beside the deferred weight gradients of the
+    proposal window; this is what the kernels do with the GPU to themselves."""
+    import importlib
+    from chainer_mask_rcnn_amd import _lib
+    ra = importlib.import_module('chainer_mask_rcnn_amd.functions.roi_align_2d')
+    lib = _lib.load()
+    t = chain.last_targets
+    rois, idx, shape = t['sample_rois'], t['sample_roi_indices'], t['feature_shape']
+    head = chain.mask_rcnn.head
+    order = getattr(rois, '_mrcnn_order', None)
+    x = torch.randn(shape, device=device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    r5 = torch.cat((idx.to(torch.float32)[:, None], rois), 1)[:, [0, 2, 1, 4, 3]].contiguous()
+    bs = max(1, head.roi_size // 7)
+    gy = None
+    for it in range(reps + 3):
+        if it == 3:
+            torch.cuda.synchronize()
+            lib.mrcnn_profile_enable(1)
+        y = ra._ROIAlign2DFn.apply(x, r5, head.roi_size, head.roi_size, head.spatial_scale, 0, bs, order)
+        if gy is None:
+            gy = torch.randn_like(y)
+        x.grad = None
+        y.backward(gy)
+    torch.cuda.synchronize()
+    prof = profile_summary()
+    lib.mrcnn_profile_enable(0)
+    return {k: dict(gbs=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1),
+                    frac_of_hbm_peak=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                    avg_launch_us=round(v['total_ms'] * 1e3 / v['launches'], 1))
+            for k, v in prof.items() if k.startswith('roi_align')}
+
+
 def pmc_traffic(kernel_name):
     """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary
     (profiles/*_pmc_fetch_write.json: separate FETCH_SIZE and WRITE_SIZE passes over this
@@ -485,6 +520,9 @@ def main():
     n_rois = chain.last_targets['n_rois']
     loss_val = float(loss.item())
     elapsed = max_over_ranks(elapsed)
+    roi_iso = None
+    if not args.no_profile and 'sample_roi_indices' in chain.last_targets:
+        roi_iso = roi_align_isolated(chain, device)
 
     # ---- second measurement: rotating host batches, image upload inside the timed region ----
     rotating = None
@@ -708,6 +746,8 @@ def main():
                                                  frac_of_hbm_peak=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                                                  avg_launch_us=round(v['total_ms'] * 1e3 / v['launches'], 1))
                                          for k, v in timed.items() if k.startswith('roi_align')},
+                            # the same two kernels with the GPU to themselves (same RoIs, after the timed region)
+                            hbm_kernels_isolated=roi_iso,
                             kernels={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
                                              tflops=round(v['flops'] / (v['total_ms'] * 1e-3) / 1e12, 2)
                                              if v['flops'] else None,

@@ -175,7 +175,8 @@ class MaskRCNNTrainChain(torch.nn.Module):
                        'roi_mask_loss': roi_mask_loss.detach(),
                        'loss': loss.detach()}
         mark('losses queued')
-        self.last_targets = {'sample_rois': sample_rois, 'gt_roi_labels': gt_roi_labels,
+        self.last_targets = {'sample_rois': sample_rois, 'sample_roi_indices': sample_roi_indices,
+                             'feature_shape': tuple(features.shape), 'gt_roi_labels': gt_roi_labels,
                              'gt_roi_masks': gt_roi_masks, 'gt_rpn_labels': gt_rpn_labels,
                              'n_rois': int(sample_rois.shape[0]),
                              'n_fg': getattr(self, '_last_n_fg', None)}   # host count, no read-back
