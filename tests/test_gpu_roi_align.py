@@ -157,14 +157,15 @@ def test_gradient_mass_full_size_property(dev):
 
 
 def test_backward_forms_agree_at_full_c2_size(dev):
-    """BASELINE configs[1] shape (2 x 1024 x 51 x 84, 1024 RoIs, 14x14 bins read with stride 2):
+    """BASELINE configs[1] shape (2 x 1024 x 51 x 84, 1024 / 1500 RoIs, 14x14 bins read with stride 2):
     the pixel-owner backward (tables + ordered entry lists) against the atomic gather form, on
     benchmark-like small RoIs and on object-sized ones; gradient mass preserved."""
     import importlib
     mod = importlib.import_module('chainer_mask_rcnn_amd.functions.roi_align_2d')
-    N, C, H, W, R = 2, 1024, 51, 84, 1024
+    N, C, H, W = 2, 1024, 51, 84
     g = torch.Generator(device='cpu').manual_seed(3)
-    for lo, hi in ((30., 200.), (32., 600.)):
+    # R = 1500: more RoIs than one scan chunk of the owner kernel (4 per thread x 256 threads)
+    for lo, hi, R in ((30., 200., 1024), (32., 600., 1500)):
         yx = torch.rand((R, 2), generator=g) * torch.tensor([760., 1290.])
         hw = torch.rand((R, 2), generator=g) * (hi - lo) + lo
         br = torch.minimum(yx + hw, torch.tensor([800., 1333.]))
