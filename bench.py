@@ -264,7 +264,7 @@ def cpu_baseline():
                 seconds_per_iteration=round(dt, 2),
                 sample=('measured C1: BASELINE configs[0] in full — 1 x 800x1333 image, %d sampled '
                         'RoIs, forward + backward through oracle/np_step.py (NumPy im2col + BLAS on '
-                        '%d threads of %d logical cores, single-threaded C ROIAlign / NMS), 1 timed '
+                        '%d threads of %d logical cores, C ROIAlign on OpenMP threads, single-threaded C NMS), 1 timed '
                         'iteration after a 160x224 warm-up iteration; loss %.4f; seconds per phase: %s'
                         % (len(out['gt_roi_labels']), threads, os.cpu_count(), out['losses']['loss'],
                            phases)))
