@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libmrcnn_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -51,6 +52,7 @@ enum ProfKind {
 bool prof_enabled(int kind);
 void prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void prof_end(hipStream_t s);
+void prof_begin_ext(int kind, double flops, double bytes, hipEvent_t *start, hipEvent_t *stop);
 struct ProfScope {
     hipStream_t s_;
     bool on_;
@@ -63,6 +65,30 @@ struct ProfScope {
         if (on_) prof_end(s_);
     }
 };
+
+// Kernel-only timing of the launches issued inside the scope: launch sites call prof_take()
+// and pass the two events to hipExtLaunchKernelGGL (start = first launch of the scope, stop =
+// its `launches`-th); both are null when the kind is not timed.
+struct ProfPending { hipEvent_t ev0 = nullptr, ev1 = nullptr; int remaining = 0; };
+extern thread_local ProfPending g_prof_pending;
+struct ProfKernelScope {
+    ProfKernelScope(int kind, double flops, double bytes, int launches = 1)
+    {
+        prof_begin_ext(kind, flops, bytes, &g_prof_pending.ev0, &g_prof_pending.ev1);
+        g_prof_pending.remaining = launches;
+    }
+    ~ProfKernelScope() { g_prof_pending = ProfPending(); }
+};
+static inline void prof_take(hipEvent_t *start, hipEvent_t *stop)
+{
+    *start = g_prof_pending.ev0;
+    g_prof_pending.ev0 = nullptr;
+    *stop = nullptr;
+    if (--g_prof_pending.remaining <= 0) {
+        *stop = g_prof_pending.ev1;
+        g_prof_pending.ev1 = nullptr;
+    }
+}
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -1396,29 +1396,35 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
             p.stagger_cycles = (int)std::min<int64_t>(cyc, 1 << 20);
         }
     }
+    hipEvent_t ev0, ev1;          // kernel-only timing (ProfKernelScope of the caller), usually null
+    mrcnn::prof_take(&ev0, &ev1);
     if constexpr (MODE == WGRAD && TM == 2 && TN == 2) {
         if ((g_split_bf16 & 1) && p.perm_n == 0) {
-            hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
-                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
+            hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
+                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1, 0,
+                                  p);
             return;
         }
     }
     if constexpr (MODE == WGRAD && !MASKED) {
         if (p.perm_n > 0) {
-            hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
-                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
+            hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
+                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1, 0,
+                                  p);
             return;
         }
     }
     if constexpr (MODE == FWD && TM == TN && (TM == 1 || TM == 2)) {
         if (g_split_bf16 & (TM == 2 ? 1 : 2)) {
-            hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
-                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
+            hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
+                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1, 0,
+                                  p);
             return;
         }
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED>),
-                       dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, p);
+    hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED>),
+                       dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1, 0,
+                                  p);
 }
 
 inline bool is_masked(const GemmParams &p) { return p.mask_y != nullptr || p.in_scale != nullptr; }
@@ -1444,9 +1450,9 @@ void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
     const double bytes = 4.0 * ((double)rows * p.N + (double)rows * p.Kc + (double)p.N * kdepth);
     // profiler buckets follow the kernel SYMBOL (what rocprofv3 reports): the forward-form
     // instantiation runs forward convolutions and the transposed-filter dgrads alike
-    mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
-                              (TM >= 2 ? 0 : 1),
-                          flops, bytes, s);
+    mrcnn::ProfKernelScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
+                                    (TM >= 2 ? 0 : 1),
+                                flops, bytes);
     launch_kernel<TM, TN, MODE>(p, blocks, splits, s);
 }
 
@@ -1569,9 +1575,9 @@ bool launch_fused_tail(GemmParams p, int rows_main, hipStream_t s)
         const double kdepth = (double)p.R * p.S * (double)p.Kc;
         const double flops = 2.0 * p.M * p.N * kdepth;
         const double bytes = 4.0 * ((double)p.M * p.N + (double)p.M * p.Kc + (double)p.N * kdepth);
-        mrcnn::ProfScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
-                                  (TM >= 2 ? 0 : 1),
-                              flops, bytes, s);
+        mrcnn::ProfKernelScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
+                                        (TM >= 2 ? 0 : 1),
+                                    flops, bytes);
         launch_kernel<TM, TN, MODE>(p, main_tiles + tail_tiles * splits, 1, s);
     }
     FixParams f = {};
@@ -2120,13 +2126,15 @@ static int wgrad_impl(const float *gy, int ldg, const float *x, float *gw, int K
         p.reduce_out = gw;
         MRCNN_HIP_TRY(hipMemsetAsync(p.tile_counters, 0, sizeof(int) * (size_t)tiles, s));
     }
-    mrcnn::ProfScope prof(use_big ? mrcnn::PROF_CONV_WGRAD_128 : mrcnn::PROF_CONV_WGRAD_64,
-                          2.0 * p.M * p.N * (double)pixels,
-                          4.0 * ((double)p.M * p.N + (double)pixels * (p.M + (double)C)), s);
-    if (use_big)
-        launch_kernel<2, 2, WGRAD>(p, big, splits, s);
-    else
-        launch_kernel<1, 1, WGRAD>(p, tiles, splits, s);
+    {
+        mrcnn::ProfKernelScope prof(use_big ? mrcnn::PROF_CONV_WGRAD_128 : mrcnn::PROF_CONV_WGRAD_64,
+                                    2.0 * p.M * p.N * (double)pixels,
+                                    4.0 * ((double)p.M * p.N + (double)pixels * (p.M + (double)C)));
+        if (use_big)
+            launch_kernel<2, 2, WGRAD>(p, big, splits, s);
+        else
+            launch_kernel<1, 1, WGRAD>(p, tiles, splits, s);
+    }
     if (splits > 1 && !in_kernel) {
         const int64_t blocks = mrcnn::ceil_div(gwsz / 4, 256);   // one float4 per thread
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s,

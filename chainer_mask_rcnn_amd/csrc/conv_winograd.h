@@ -462,9 +462,11 @@ int wino_batched_gemm(const float *a, const float *b, float *out, int64_t T, int
                               : mrcnn::ceil_div(p.M, 64) * mrcnn::ceil_div(p.N, 64);
     const double flops = 2.0 * kXi * (double)T * N * Kc;
     const double bytes = 4.0 * kXi * ((double)T * N + (double)T * Kc + (double)N * Kc);
-    mrcnn::ProfScope prof(big ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_FWD_64, flops, bytes, s);
     const int rem = p.M % 128;
-    if (big && rem > 0 && rem <= 64 && p.M >= 256) {
+    const bool two_launches = big && rem > 0 && rem <= 64 && p.M >= 256;
+    mrcnn::ProfKernelScope prof(big ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_FWD_64, flops, bytes,
+                                two_launches ? 2 : 1);
+    if (two_launches) {
         // a last row tile that is at most half full (the RPN's 546 tiles of a 2 x 51 x 84 map:
         // 4 x 128 + 34) runs as 64-row tiles instead of a whole 128-row tile of mostly padding
         const int full = p.M - rem;
@@ -647,9 +649,9 @@ extern "C" int mrcnn_conv3x3_wino_wgrad(const mrcnn_conv_desc *d, const float *x
     if (int rc = set_extents(p, g.T * d->K, g.T * d->C, kc)) return rc;
     p.C = slabs;
     {
-        mrcnn::ProfScope prof(big ? mrcnn::PROF_CONV_WGRAD_128 : mrcnn::PROF_CONV_WGRAD_64,
-                              2.0 * kXi * (double)kc * (double)g.T,
-                              4.0 * kXi * ((double)kc * splits + (double)g.T * (d->K + d->C)), s);
+        mrcnn::ProfKernelScope prof(big ? mrcnn::PROF_CONV_WGRAD_128 : mrcnn::PROF_CONV_WGRAD_64,
+                                    2.0 * kXi * (double)kc * (double)g.T,
+                                    4.0 * kXi * ((double)kc * splits + (double)g.T * (d->K + d->C)));
         if (big) launch_kernel<2, 2, WGRAD>(p, tiles, splits, s, kXi);
         else launch_kernel<1, 1, WGRAD>(p, tiles, splits, s, kXi);
     }

@@ -18,6 +18,7 @@ void set_error(const char *fmt, ...)
 }
 
 // ---- kernel timer -------------------------------------------------------------------
+thread_local ProfPending g_prof_pending;
 namespace {
 struct ProfRec { hipEvent_t start, stop; int kind; double flops, bytes; };
 std::mutex g_prof_mu;
@@ -60,6 +61,27 @@ void prof_begin(int kind, double flops, double bytes, hipStream_t s)
     r.bytes = bytes;
     if (timed) (void)hipEventRecord(r.start, s);
     g_prof_recs.push_back(r);
+}
+
+// Dispatch-timestamp timing: the record's events are handed to hipExtLaunchKernelGGL, which
+// stamps them from the kernel's own dispatch packet — no marker packets on the stream (an
+// hipEventRecord pair costs ~7 us of queue time per launch).  Null events when the kind is not
+// timed in the current mode (the launch then behaves like hipLaunchKernelGGL).
+void prof_begin_ext(int kind, double flops, double bytes, hipEvent_t *start, hipEvent_t *stop)
+{
+    *start = *stop = nullptr;
+    if (g_prof_mode == 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    const bool timed = prof_timed(kind);
+    r.start = timed ? get_event() : nullptr;
+    r.stop = timed ? get_event() : nullptr;
+    r.kind = kind;
+    r.flops = flops;
+    r.bytes = bytes;
+    g_prof_recs.push_back(r);
+    *start = r.start;
+    *stop = r.stop;
 }
 
 void prof_end(hipStream_t s)

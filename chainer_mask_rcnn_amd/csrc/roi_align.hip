@@ -802,17 +802,19 @@ extern "C" int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *
     const int bins = R * OH * OW;
     hipStream_t s = mrcnn::as_stream(stream);
     // algorithmic bytes: write R*OH*OW*C, read the feature maps once
-    mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_FWD, 0.,
-                          4.0 * ((double)bins * C + (double)N * H * W * C), s);
+    hipEvent_t ev0, ev1;      // kernel-only timing from the dispatch packet (bench.py roofline)
+    mrcnn::prof_begin_ext(mrcnn::PROF_ROI_ALIGN_FWD, 0.,
+                          4.0 * ((double)bins * C + (double)N * H * W * C), &ev0, &ev1);
     if (C % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0)) {
         const int cv = C / 4;
-        hipLaunchKernelGGL(roi_align_fwd_kernel<float4>, dim3((R * OH + 7) / 8 * 8),
-                           dim3(pick_threads(cv)), 0, s, (const float4 *)x, rois, (float4 *)y, H, W,
-                           cv, PH, PW, spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH, order);
+        hipExtLaunchKernelGGL(roi_align_fwd_kernel<float4>, dim3((R * OH + 7) / 8 * 8),
+                              dim3(pick_threads(cv)), 0, s, ev0, ev1, 0, (const float4 *)x, rois,
+                              (float4 *)y, H, W, cv, PH, PW, spatial_scale, sampling_ratio, OH, OW,
+                              bin_stride, R * OH, order);
     } else {
-        hipLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3((R * OH + 7) / 8 * 8),
-                           dim3(pick_threads(C)), 0, s, x, rois, y, H, W, C, PH, PW, spatial_scale,
-                           sampling_ratio, OH, OW, bin_stride, R * OH, order);
+        hipExtLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3((R * OH + 7) / 8 * 8),
+                              dim3(pick_threads(C)), 0, s, ev0, ev1, 0, x, rois, y, H, W, C, PH, PW,
+                              spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH, order);
     }
     return mrcnn::check_launch("roi_align_fwd");
 }
@@ -869,22 +871,24 @@ extern "C" int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float 
         (uintptr_t)ws % 16 == 0) {
         // pixel-owner form: every gx element is written exactly once, no zero-fill.
         // algorithmic bytes: read R*OH*OW*C, write the feature-map gradient
-        mrcnn::ProfScope prof(mrcnn::PROF_ROI_ALIGN_BWD, 0.,
-                              4.0 * ((double)bins * C + (double)N * H * W * C), s);
+        hipEvent_t ev0, ev1;  // start of the table kernel .. end of the owner kernel, dispatch timestamps
+        mrcnn::prof_begin_ext(mrcnn::PROF_ROI_ALIGN_BWD, 0.,
+                              4.0 * ((double)bins * C + (double)N * H * W * C), &ev0, &ev1);
         const OwnerWs w = owner_ws(H, W, R, OH, OW);
         int4 *ext = (int4 *)((char *)ws + w.ext);
         float *Ay = (float *)((char *)ws + w.ay);
         float *Bx = (float *)((char *)ws + w.bx);
-        hipLaunchKernelGGL(roi_bwd_tables_kernel, dim3(R), dim3(256), 0, s, rois, H, W, w.Wp, PH, PW,
-                           OH, OW, bin_stride, spatial_scale, sampling_ratio, ext, Ay, Bx);
+        hipExtLaunchKernelGGL(roi_bwd_tables_kernel, dim3(R), dim3(256), 0, s, ev0, nullptr, 0, rois, H,
+                              W, w.Wp, PH, PW, OH, OW, bin_stride, spatial_scale, sampling_ratio, ext,
+                              Ay, Bx);
         const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
         if (vec)
-            hipLaunchKernelGGL(roi_align_bwd_owner_kernel<float4>, grid, dim3(pick_threads(C / 4)), 0,
-                               s, (const float4 *)gy, ext, Ay, Bx, (float4 *)gx, R, N, H, W, w.Wp,
-                               C / 4, OH, OW);
+            hipExtLaunchKernelGGL(roi_align_bwd_owner_kernel<float4>, grid, dim3(pick_threads(C / 4)),
+                                  0, s, nullptr, ev1, 0, (const float4 *)gy, ext, Ay, Bx, (float4 *)gx,
+                                  R, N, H, W, w.Wp, C / 4, OH, OW);
         else
-            hipLaunchKernelGGL(roi_align_bwd_owner_kernel<float>, grid, dim3(pick_threads(C)), 0, s,
-                               gy, ext, Ay, Bx, gx, R, N, H, W, w.Wp, C, OH, OW);
+            hipExtLaunchKernelGGL(roi_align_bwd_owner_kernel<float>, grid, dim3(pick_threads(C)), 0, s,
+                                  nullptr, ev1, 0, gy, ext, Ay, Bx, gx, R, N, H, W, w.Wp, C, OH, OW);
         return mrcnn::check_launch("roi_align_bwd");
     }
     MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * H * W * C, s));
