@@ -87,7 +87,9 @@ int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *y,
  * form — per RoI the patch extent and the separable bilinear weights of every feature row and
  * column are tabulated once, then every gx pixel is summed in registers over the RoIs that cover
  * it (in RoI order, bins in row-major order) and stored once: no atomics, no zero-fill,
- * bit-reproducible, ~10x faster at the C2 shape (H, W <= 65535; otherwise the first form runs). */
+ * bit-reproducible, ~10x faster at the C2 shape (H, W <= 65535; otherwise the first form runs).
+ * A bin is applied to the 8-pixel row tile it touches with weight 0 on the pixels it does not
+ * touch: identical sums for finite gy; a non-finite gy element reaches those neighbours too. */
 int64_t mrcnn_roi_align_bwd_workspace_bytes(int N, int H, int W, int R, int PH, int PW,
                                             int bin_stride);
 int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float *gx,
