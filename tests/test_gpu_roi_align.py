@@ -119,6 +119,38 @@ def test_processing_order_does_not_change_the_result(dev):
                        axes='yx', order=torch.zeros(R, dtype=torch.int64, device=dev))
 
 
+@pytest.mark.parametrize('sr', [0, 1, 2])
+def test_numerical_gradient_on_the_reference_test_geometry(dev, sr):
+    """The reference's own backward test (tests/functions_tests/test_roi_align_2d.py:18-41,
+    :89-107: chainer.gradient_check.check_backward with atol 5e-4, rtol 5e-3 on a 3x3x12x8
+    input, four RoIs incl. a degenerate one, 5x7 bins, scale 0.6): central differences through the
+    HIP forward along random directions against the HIP backward (ROIAlign is linear in x)."""
+    rng = np.random.RandomState(10 + sr)
+    N, C = 3, 3
+    x = np.arange(N * C * 12 * 8, dtype=np.float32).reshape((N, C, 12, 8))
+    rng.shuffle(x.reshape(-1))
+    x = 2 * x / x.size - 1
+    rois = np.array([[0, 1, 1, 6, 6], [2, 6, 2, 7, 11], [1, 3, 1, 5, 10], [0, 3, 3, 3, 3]], np.float32)
+    gy = rng.uniform(-1, 1, (4, C, 5, 7)).astype(np.float32)
+    rd, gyd = torch.tensor(rois, device=dev), torch.tensor(gy, device=dev)
+
+    def fwd(a):
+        return F.roi_align_2d(torch.tensor(a, device=dev), rd, outh=5, outw=7, spatial_scale=0.6,
+                              sampling_ratio=sr)
+
+    xt = torch.tensor(x, device=dev, requires_grad=True)
+    y = F.roi_align_2d(xt, rd, outh=5, outw=7, spatial_scale=0.6, sampling_ratio=sr)
+    assert y.dtype == torch.float32 and tuple(y.shape) == gy.shape
+    y.backward(gyd)
+    gx = xt.grad.double().cpu().numpy()
+    eps = 1e-2
+    for _ in range(5):
+        d = rng.standard_normal(x.shape).astype(np.float32)
+        num = ((fwd(x + eps * d).double() - fwd(x - eps * d).double()) * gyd.double()).sum().item() / (2 * eps)
+        ana = float((gx * d).sum())
+        assert abs(num - ana) <= 5e-4 + 5e-3 * abs(ana), (num, ana)
+
+
 def test_out_of_range_samples_skipped(dev):
     x = np.ones((1, 4, 4, 4), np.float32)
     rois = np.array([[0, 0, 0, 200, 200], [0, -50, -50, 2, 2]], np.float32)
