@@ -180,6 +180,40 @@ def test_affine_channel_2d_golden(dev, golden_dir):
     np.testing.assert_allclose(bt.grad.cpu().numpy(), d['gb'], rtol=1e-4, atol=1e-5)
 
 
+def test_affine_channel_2d_numerical_gradient_reference_geometry(dev):
+    """The reference's own backward test (tests/functions_tests/test_affine_channel_2d.py:16-31,
+    check_backward with atol 5e-4, rtol 5e-3): 3x3x12x8 input, W and b of shape (1, C, 1, 1);
+    central differences through the HIP forward along random directions in (x, W, b) against the
+    HIP backward."""
+    rng = np.random.RandomState(3)
+    N, C = 3, 3
+    x = np.arange(N * C * 12 * 8, dtype=np.float32).reshape((N, C, 12, 8))
+    rng.shuffle(x.reshape(-1))
+    x = 2 * x / x.size - 1
+    W = rng.random_sample((1, C, 1, 1)).astype(np.float32)
+    b = rng.random_sample((1, C, 1, 1)).astype(np.float32)
+    gy = rng.uniform(-1, 1, x.shape).astype(np.float32)
+    xt, wt, bt = _t(x, dev, True), _t(W, dev, True), _t(b, dev, True)
+    y = F.affine_channel_2d(xt, wt, bt)
+    assert y.dtype == torch.float32 and tuple(y.shape) == x.shape
+    y.backward(_t(gy, dev))
+    gx, gW, gb = (t.grad.double().cpu().numpy() for t in (xt, wt, bt))
+
+    def fwd(a, w_, b_):
+        return F.affine_channel_2d(_t(a, dev), _t(w_, dev), _t(b_, dev)).double().cpu().numpy()
+
+    eps = 1e-2
+    for _ in range(5):
+        dx = rng.standard_normal(x.shape).astype(np.float32)
+        dW = rng.standard_normal(W.shape).astype(np.float32)
+        db = rng.standard_normal(b.shape).astype(np.float32)
+        num = ((fwd(x + eps * dx, W + eps * dW, b + eps * db) -
+                fwd(x - eps * dx, W - eps * dW, b - eps * db)) * gy).sum() / (2 * eps)
+        ana = float((gx * dx).sum() + (gW * dW).sum() + (gb * db).sum())
+        # y = x * W + b is bilinear: the central difference has no second-order error in eps
+        assert abs(num - ana) <= 5e-4 + 5e-3 * abs(ana), (num, ana)
+
+
 def test_conv_linearity_at_full_size(dev):
     """Size-independent property at the BASELINE C2 res5 shape (1024 RoIs):
     conv(a*x1 + x2) == a*conv(x1) + conv(x2) to fp32 round-off, plus a spot check
