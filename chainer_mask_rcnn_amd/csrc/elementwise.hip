@@ -412,6 +412,94 @@ extern "C" int mrcnn_head_tail_bwd(const float *g_pool, const float *g_rows, con
     return mrcnn::check_launch("head_tail_bwd");
 }
 
+// ---- row-sparse backward of a 3x3 / stride 1 / pad 1 convolution ---------------------------
+// The RPN's losses ignore all but the <= 256 sampled anchors of an image
+// (models/mask_rcnn_train_chain.py:150-166, AnchorTargetCreator label -1), so the gradient that
+// reaches conv1's output (models/region_proposal_network.py:75-80) is exactly zero outside the
+// <= 512 map positions of those anchors.  The backward then needs only those rows: their 3x3
+// input patches are gathered, weight and data gradients are ONE 1x1-shaped GEMM each over
+// (rows x 9C) operands (6 % of the dense work), and the patch gradients are summed back per map
+// pixel in a fixed tap order (pixel-owner form, no atomics).
+namespace {
+// grid (rows, 10): y < 9: tap (r, s) = (y / 3, y % 3) of the row's patch; y == 9: its gradient row
+__global__ void __launch_bounds__(256)
+sparse3x3_gather_kernel(const float4 *__restrict__ x, const float4 *__restrict__ g,
+                        const int32_t *__restrict__ rows, int H, int W, int C4, int K4,
+                        float4 *__restrict__ patches, float4 *__restrict__ g_rows)
+{
+    const int i = blockIdx.x, t = blockIdx.y;
+    const int p = rows[i];
+    if (t == 9) {
+        const float4 *src = g + (int64_t)p * K4;
+        float4 *dst = g_rows + (int64_t)i * K4;
+        for (int c = threadIdx.x; c < K4; c += blockDim.x) dst[c] = src[c];
+        return;
+    }
+    const int px = p % W, py = (p / W) % H, n = p / (W * H);
+    const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+    const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    const float4 *src = x + (((int64_t)n * H + yy) * W + xx) * C4;
+    float4 *dst = patches + ((int64_t)i * 9 + t) * C4;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = threadIdx.x; c < C4; c += blockDim.x) dst[c] = in ? src[c] : zero;
+}
+
+// one workgroup = one map pixel q: gx[q] = sum over taps (r, s), in that order, of the patch
+// gradient of the sampled position q - (r - 1, s - 1) (lookup: position -> row or -1)
+__global__ void __launch_bounds__(256)
+sparse3x3_scatter_kernel(const float4 *__restrict__ gp, const int32_t *__restrict__ lookup, int H,
+                         int W, int C4, float4 *__restrict__ gx)
+{
+    const int q = blockIdx.x;
+    const int qx = q % W, qy = (q / W) % H, n = q / (W * H);
+    int src[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = qy - (t / 3 - 1), xx = qx - (t % 3 - 1);
+        src[t] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                     ? lookup[((int64_t)n * H + yy) * W + xx] : -1;
+    }
+    for (int c = threadIdx.x; c < C4; c += blockDim.x) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (src[t] < 0) continue;
+            const float4 v = gp[((int64_t)src[t] * 9 + t) * C4 + c];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        gx[(int64_t)q * C4 + c] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int mrcnn_sparse3x3_gather(const float *x, const float *g, const int32_t *rows,
+                                      int n_rows, int N, int H, int W, int C, int K,
+                                      float *patches, float *g_rows, void *stream)
+{
+    MRCNN_REQUIRE(n_rows >= 0 && N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && C % 4 == 0 &&
+                      K % 4 == 0, "sparse3x3_gather: bad shape");
+    if (n_rows == 0) return 0;
+    MRCNN_REQUIRE(x && g && rows && patches && g_rows, "sparse3x3_gather: null pointer");
+    mrcnn::ProfScope prof(mrcnn::PROF_ELEMENTWISE, 0.,
+                          8.0 * (double)n_rows * (9.0 * C + K), mrcnn::as_stream(stream));
+    hipLaunchKernelGGL(sparse3x3_gather_kernel, dim3(n_rows, 10), dim3(256), 0,
+                       mrcnn::as_stream(stream), (const float4 *)x, (const float4 *)g, rows, H, W,
+                       C / 4, K / 4, (float4 *)patches, (float4 *)g_rows);
+    return mrcnn::check_launch("sparse3x3_gather");
+}
+
+extern "C" int mrcnn_sparse3x3_scatter(const float *g_patches, const int32_t *lookup, int N, int H,
+                                       int W, int C, float *gx, void *stream)
+{
+    MRCNN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "sparse3x3_scatter: bad shape");
+    MRCNN_REQUIRE((int64_t)N * H * W < (int64_t)INT32_MAX, "sparse3x3_scatter: map too large");
+    MRCNN_REQUIRE(g_patches && lookup && gx, "sparse3x3_scatter: null pointer");
+    hipLaunchKernelGGL(sparse3x3_scatter_kernel, dim3(N * H * W), dim3(256), 0,
+                       mrcnn::as_stream(stream), (const float4 *)g_patches, lookup, H, W, C / 4,
+                       (float4 *)gx);
+    return mrcnn::check_launch("sparse3x3_scatter");
+}
+
 extern "C" int mrcnn_sgd_momentum_wd_ex(float *p, float *g, float *v, int64_t n, float lr,
                                         float momentum, float wd, float grad_scale, int zero_grad,
                                         void *stream)

@@ -74,6 +74,86 @@ _CONV_RECORDS_GRAPH = True
 RELU_TAP = None
 
 
+# ---- row-sparse backward of a 3x3 convolution (include/mrcnn_hip.h "row-sparse backward") -------
+# The RPN's losses ignore every anchor but the <= 256 sampled ones per image, so the gradient
+# reaching conv1's output is exactly zero outside their map positions; the train chain, which
+# builds the anchor targets on the host, hands the positions to the RPN in a ``SparseRows``.
+SPARSE_CONV_BACKWARD = True
+
+
+class SparseRows(object):
+    """Positions of a (N, H, W) map outside which the gradient arriving at a convolution's output
+    is EXACTLY zero: ``rows`` int32 device tensor of sorted indices into N*H*W, ``lookup`` int32
+    device tensor (N*H*W) position -> index into rows or -1, ``n`` = len(rows) (host int).
+    One-shot: the backward that uses it clears it; a fresh forward clears it as well."""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.rows = self.lookup = None
+        self.n = 0
+
+    def set(self, rows, lookup, n):
+        self.rows, self.lookup, self.n = rows, lookup, int(n)
+
+    @staticmethod
+    def host_tables(positions, size):
+        """(rows int32 sorted unique, lookup int32 (size,)) NumPy arrays from map positions."""
+        import numpy as np
+        rows = np.unique(np.asarray(positions, np.int64)).astype(np.int32)
+        lookup = np.full((int(size),), -1, np.int32)
+        lookup[rows] = np.arange(len(rows), dtype=np.int32)
+        return rows, lookup
+
+
+_SPARSE_HINT = None
+
+
+class sparse_output_grad(object):
+    """``with sparse_output_grad(hint): y = conv2d(...)`` — the 3x3 / stride 1 / pad 1 convolutions
+    recorded inside may take their backward from ``hint`` (a ``SparseRows`` filled before backward)."""
+
+    def __init__(self, hint):
+        self.hint = hint
+
+    def __enter__(self):
+        global _SPARSE_HINT
+        self.prev, _SPARSE_HINT = _SPARSE_HINT, self.hint
+        return self.hint
+
+    def __exit__(self, *exc):
+        global _SPARSE_HINT
+        _SPARSE_HINT = self.prev
+        return False
+
+
+def _sparse3x3_backward(ctx, d, x, Wc, g, hint, need_x, need_w, need_b):
+    """Backward of a 3x3 / stride 1 / pad 1 convolution whose output gradient ``g`` (already through
+    ReLU) is zero outside ``hint.rows``: the 1x1 problem (N = rows, C = 9 C_in) on gathered patches."""
+    dev, n = g.device, hint.n
+    patches = torch.empty((n, 9 * d.C), dtype=torch.float32, device=dev)
+    g_rows = torch.empty((n, d.K), dtype=torch.float32, device=dev)
+    _lib.call('mrcnn_sparse3x3_gather', _lib.ptr(x), _lib.ptr(g), _lib.ptr(hint.rows), n,
+              d.N, d.H, d.W, d.C, d.K, _lib.ptr(patches), _lib.ptr(g_rows), _lib.stream_ptr())
+    d1 = ConvDesc(n, 1, 1, 9 * d.C, d.K, 1, 1, 1, 0, 1, 1)
+    gx = gW = gb = None
+    if need_w:
+        gW = _wgrad_raw(d1, patches, g_rows, ctx.W_param, None, None)
+    if need_x:
+        gp = _dgrad_raw(d1, g_rows, Wc, None, None)          # (rows, 3, 3, C) patch gradients
+        gx = empty_nhwc((d.N, d.C, d.H, d.W), dev)
+        _lib.call('mrcnn_sparse3x3_scatter', _lib.ptr(gp), _lib.ptr(hint.lookup), d.N, d.H, d.W,
+                  d.C, _lib.ptr(gx), _lib.stream_ptr())
+    if need_b:
+        b = ctx.b_param
+        direct = _direct_grad(b)
+        gbt = b.grad if direct else torch.empty((d.K,), dtype=torch.float32, device=dev)
+        _colsum(_lib.ptr(g_rows), n, d.K, gbt, dev)
+        gb = None if direct else gbt
+    return gx, gW, gb
+
+
 class _Conv2dFn(torch.autograd.Function):
     """y = relu?( affine?( conv(x, W) + b? ) + residual? )"""
 
@@ -108,6 +188,8 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.relu = relu
         ctx.has_bias = b is not None
         ctx.has_res = residual is not None
+        ctx.sparse_hint = _SPARSE_HINT if (d.R == 3 and d.S == 3 and stride == 1 and pad == 1 and
+                                           scale is None and residual is None) else None
         ctx.W_param = W
         ctx.b_param = b
         ctx.save_for_backward(x, Wc, scale, y if relu else None)
@@ -127,6 +209,11 @@ class _Conv2dFn(torch.autograd.Function):
         g = epilogue_bwd(gr, None, scale) if scale is not None else gr
         M = d.N * d.P * d.Q
         gx = gW = gb = None
+        hint = ctx.sparse_hint
+        if hint is not None and hint.rows is not None and hint.n > 0 and SPARSE_CONV_BACKWARD:
+            gx, gW, gb = _sparse3x3_backward(ctx, d, x, Wc, g, hint, need_x, need_w, need_b)
+            hint.clear()
+            return gx, gW, gb, None, None, None, None, None, None
         if need_w:
             W = ctx.W_param
             if ctx.wino and WINOGRAD_WGRAD:

@@ -95,6 +95,11 @@ class MaskRCNNTrainChain(torch.nn.Module):
         # order, so the sampled sets are identical.  Off by default: at COCO sizes the host
         # creators already overlap with the GPU and the device path adds read-backs.
         self.device_targets = False
+        # The RPN losses ignore all but the sampled anchors, so conv1 of the RPN receives a gradient
+        # that is exactly zero outside <= 256 positions per image: its backward runs on those rows
+        # only (same sums, 6 % of the dense GEMM work; functions/conv.py SparseRows).  Host-target
+        # path only (the positions are known on the host there without a read-back).
+        self.sparse_rpn_backward = True
         self.host_timeline = None          # developer aid: list of (label, perf_counter) marks
         # The image batch of the NEXT iteration (device tensor, or a callable returning it / None),
         # when the caller already has it — a resident batch, the input pipeline's prefetched one.
@@ -280,9 +285,28 @@ class MaskRCNNTrainChain(torch.nn.Module):
                 gt_rpn_loc, gt_rpn_label = atc(bbox, anchor_h, img_size)
             gt_rpn_locs.append(gt_rpn_loc)
             gt_rpn_labels.append(gt_rpn_label)
-        gt_rpn_locs, gt_rpn_labels = _upload_many(
-            [np.concatenate(gt_rpn_locs, axis=0), np.concatenate(gt_rpn_labels, axis=0)],
-            [torch.float32, torch.int32], dev)
+        # Both RPN losses ignore every anchor with label -1 (:150-166), so the gradient of the RPN's
+        # conv1 output is exactly zero outside the map positions of the sampled anchors: hand
+        # those positions to its backward (functions/conv.py: SparseRows; anchor index =
+        # position * A + a, utils/bbox.py enumerate_shifted_anchor)
+        extra, extra_dt = [], []
+        rpn = self.mask_rcnn.rpn
+        hint = getattr(rpn, 'grad_rows', None)
+        n_rows = 0
+        if hint is not None and self.sparse_rpn_backward:
+            from ..functions.conv import SparseRows
+            hw = int(features.shape[2] * features.shape[3])
+            pos = [np.flatnonzero(np.asarray(lab) >= 0) // rpn.n_anchor + i * hw
+                   for i, lab in enumerate(gt_rpn_labels)]
+            rows_h, lookup_h = SparseRows.host_tables(np.concatenate(pos), hw * len(gt_rpn_labels))
+            n_rows = len(rows_h)
+            extra, extra_dt = [rows_h, lookup_h], [torch.int32, torch.int32]
+        up_all = _upload_many(
+            [np.concatenate(gt_rpn_locs, axis=0), np.concatenate(gt_rpn_labels, axis=0)] + extra,
+            [torch.float32, torch.int32] + extra_dt, dev)
+        gt_rpn_locs, gt_rpn_labels = up_all[0], up_all[1]
+        if n_rows > 0:
+            hint.set(up_all[2], up_all[3], n_rows)
         mark('rpn targets')
         return (rpn_locs, rpn_scores, sample_rois, sample_roi_indices, gt_roi_locs, gt_roi_labels,
                 gt_roi_masks, gt_rpn_locs, gt_rpn_labels, roi_cls_locs, roi_scores, roi_masks, mask_rows)

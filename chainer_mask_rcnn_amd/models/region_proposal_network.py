@@ -50,6 +50,11 @@ class RegionProposalNetwork(torch.nn.Module):
         self.loc = _ConvView(self.loc_score, 0, 4 * A)
         self.score = _ConvView(self.loc_score, 4 * A, 5 * A)
         self._anchor_cache = {}
+        # map positions outside which the gradient of conv1's output is exactly zero (the sampled
+        # anchors of the RPN losses): filled by MaskRCNNTrainChain where the anchor targets are
+        # built, consumed by conv1's backward (functions/conv.py: SparseRows)
+        from ..functions.conv import SparseRows
+        self.grad_rows = SparseRows()
 
     def _anchor(self, hh, ww, device):
         key = (hh, ww, str(device))
@@ -64,7 +69,10 @@ class RegionProposalNetwork(torch.nn.Module):
         n, _, hh, ww = x.shape
         A = self.n_anchor
         _, anchor = self._anchor(hh, ww, x.device)
-        h = self.conv1(x, relu=True)
+        from ..functions.conv import sparse_output_grad
+        self.grad_rows.clear()
+        with sparse_output_grad(self.grad_rows):
+            h = self.conv1(x, relu=True)
         out = self.loc_score(h)                               # (N, 5A(+pad), H, W), NHWC
         nhwc = out.permute(0, 2, 3, 1)
         rpn_locs = nhwc[..., :4 * A].reshape(n, -1, 4)

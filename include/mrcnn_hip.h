@@ -96,6 +96,23 @@ int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float *gx,
                            int N, int H, int W, int C, int R, int PH, int PW, int bin_stride,
                            float spatial_scale, int sampling_ratio, void *ws, void *stream);
 
+/* ---- row-sparse backward of a 3x3 / stride 1 / pad 1 convolution --------------------------
+ * The reference back-propagates the RPN losses through conv1 of
+ * models/region_proposal_network.py:75-80 densely, although the losses ignore every anchor but
+ * the <= 256 sampled ones per image (models/mask_rcnn_train_chain.py:150-166): the gradient of
+ * conv1's output is exactly zero outside their map positions.  With the list of those positions
+ * (`rows`, sorted indices into N*H*W, and `lookup`, position -> row or -1; both built where the
+ * anchor targets are) the backward is: gather the rows' 3x3 input patches and gradient rows,
+ * run weight and data gradient as the 1x1 problem (N = n_rows, C = 9*C_in) through
+ * mrcnn_conv2d_wgrad / mrcnn_conv2d_dgrad_wt, and sum the patch gradients back per map pixel in
+ * a fixed tap order (every gx element written once, no atomics).  x (N,H,W,C), g (N,H,W,K) NHWC,
+ * patches (n_rows, 3, 3, C), g_rows (n_rows, K), g_patches (n_rows, 3, 3, C), gx (N,H,W,C). */
+int mrcnn_sparse3x3_gather(const float *x, const float *g, const int32_t *rows, int n_rows,
+                           int N, int H, int W, int C, int K, float *patches, float *g_rows,
+                           void *stream);
+int mrcnn_sparse3x3_scatter(const float *g_patches, const int32_t *lookup, int N, int H, int W,
+                            int C, float *gx, void *stream);
+
 /* ---- AffineChannel2D ---------------------------------------------------- */
 /* Replaces AffineChannel2DFunction.forward / backward
  * (functions/affine_channel_2d.py:10-22, :38-56).  x,y (M,C) NHWC rows,

@@ -214,6 +214,47 @@ def test_affine_channel_2d_numerical_gradient_reference_geometry(dev):
         assert abs(num - ana) <= 5e-4 + 5e-3 * abs(ana), (num, ana)
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 13, 17, 48), (2, 1024, 51, 84, 1024)])
+def test_row_sparse_3x3_backward_equals_dense(dev, shape):
+    """conv 3x3 / stride 1 / pad 1 + bias + ReLU whose output gradient is zero outside a set of map
+    positions (the RPN's conv1 under the sampled-anchor losses): the row-sparse backward (gathered
+    patches, 1x1-shaped GEMMs, pixel-owner scatter) against the dense backward of the same node —
+    gx, gW, gb within 1e-4 of the tensor scale (different summation order only); the hint is
+    one-shot.  Second shape = the RPN's at BASELINE configs[1] (positions incl. map corners)."""
+    from chainer_mask_rcnn_amd.functions import conv as conv_mod
+    N, C, H, W, K = shape
+    g = torch.Generator(device='cpu').manual_seed(C + H)
+    x = torch.randn((N, H, W, C), generator=g).to(dev).permute(0, 3, 1, 2)
+    Wt = (torch.randn((K, 3, 3, C), generator=g) / (3 * C ** 0.5)).to(dev).permute(0, 3, 1, 2)
+    b = (torch.randn((K,), generator=g) * 0.1).to(dev)
+    n_pos = min(256, H * W // 3)
+    pos = np.concatenate([np.random.RandomState(i).choice(H * W, n_pos, replace=False) + i * H * W
+                          for i in range(N)])
+    pos = np.concatenate([pos, [0, W - 1, (H - 1) * W, H * W - 1, N * H * W - 1]])
+    rows_h, lookup_h = conv_mod.SparseRows.host_tables(pos, N * H * W)
+    gy = torch.zeros((N * H * W, K), device=dev)
+    gy[torch.tensor(rows_h.astype(np.int64), device=dev)] = \
+        torch.randn((len(rows_h), K), generator=g).to(dev)
+    gy = gy.reshape(N, H, W, K).permute(0, 3, 1, 2)
+
+    def run(sparse):
+        xt, wt, bt = (t.clone().requires_grad_(True) for t in (x, Wt, b))
+        hint = conv_mod.SparseRows()
+        with conv_mod.sparse_output_grad(hint):
+            y = F.conv2d(xt, wt, bt, 1, 1, relu=True)
+        if sparse:
+            hint.set(torch.tensor(rows_h, device=dev), torch.tensor(lookup_h, device=dev), len(rows_h))
+        y.backward(gy)
+        assert hint.rows is None            # consumed (or never set)
+        return xt.grad, wt.grad, bt.grad
+
+    dense, sparse = run(False), run(True)
+    for a, s_ in zip(dense, sparse):
+        scale = float(a.abs().max())
+        assert scale > 0
+        assert float((a - s_).abs().max()) <= 1e-4 * scale
+
+
 def test_conv_linearity_at_full_size(dev):
     """Size-independent property at the BASELINE C2 res5 shape (1024 RoIs):
     conv(a*x1 + x2) == a*conv(x1) + conv(x2) to fp32 round-off, plus a spot check
