@@ -43,6 +43,7 @@ SIGNATURES = {
     'mrcnn_sparse3x3_gather': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp]),
     'mrcnn_sparse3x3_scatter': (c_int, [c_vp, c_vp] + [c_int] * 4 + [c_vp, c_vp]),
     'mrcnn_roi_align_bwd_ex': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 8 + [c_f32, c_int, c_vp, c_vp]),
+    'mrcnn_roi_align_bwd_ws': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 8 + [c_f32, c_int, c_vp, c_i64, c_vp]),
     'mrcnn_affine_fwd': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
     'mrcnn_colsum_workspace_bytes': (c_i64, [c_int]),
     'mrcnn_affine_bwd': (c_int, [c_vp] * 6 + [c_i64, c_int, c_vp, c_vp]),
@@ -138,11 +139,16 @@ class MrcnnHipError(RuntimeError):
     pass
 
 
+_load_error = None   # a failed MRCNN_TUNE application: load() keeps raising it (see load())
+
+
 def load():
     """Load libmrcnn_hip.so (built by ``__graft_entry__.build()``)."""
-    global _lib
+    global _lib, _load_error
     if _lib is not None:
         return _lib
+    if _load_error is not None:
+        raise _load_error
     if not os.path.exists(LIB_PATH):
         raise MrcnnHipError(
             'libmrcnn_hip.so not found at %s — build it with '
@@ -153,9 +159,11 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     # MRCNN_TUNE="name=value,...": mrcnn_set_tuning knobs applied when the library is loaded
-    # (e.g. MRCNN_TUNE=split_bf16=3 selects the opt-in split-operand GEMM kernels)
+    # (e.g. MRCNN_TUNE=split_bf16=0 selects the fp32-MFMA GEMM kernels).  Every entry is parsed
+    # before any is applied; a knob the library rejects leaves the process-wide library state
+    # half-tuned, so the error is remembered and every later load() raises it again.
+    knobs = []
     for kv in os.environ.get('MRCNN_TUNE', '').split(','):
         if not kv.strip():
             continue
@@ -164,10 +172,20 @@ def load():
             value = int(v)
         except ValueError:
             sep = ''
-        if not sep:
-            _lib = None
-            raise MrcnnHipError("MRCNN_TUNE: expected 'name=integer[,name=integer...]', got %r" % kv)
-        set_tuning(k.strip(), value)
+        if not sep or not k.strip():
+            _load_error = MrcnnHipError(
+                "MRCNN_TUNE: expected 'name=integer[,name=integer...]', got %r" % kv)
+            raise _load_error
+        knobs.append((k.strip(), value))
+    for k, value in knobs:
+        rc = lib.mrcnn_set_tuning(k.encode(), int(value))
+        if rc != 0:
+            msg = lib.mrcnn_last_error()
+            _load_error = MrcnnHipError('MRCNN_TUNE: set_tuning(%s=%d) failed (rc=%d): %s; knobs '
+                                        'applied before it stay set — fix the variable and restart'
+                                        % (k, value, rc, msg.decode() if msg else ''))
+            raise _load_error
+    _lib = lib
     return lib
 
 

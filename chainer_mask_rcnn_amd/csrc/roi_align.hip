@@ -859,8 +859,20 @@ extern "C" int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float 
                                       float spatial_scale, int sampling_ratio, void *ws,
                                       void *stream)
 {
+    // (no extent given: the caller vouches for mrcnn_roi_align_bwd_workspace_bytes of THIS header)
+    return mrcnn_roi_align_bwd_ws(gy, rois, gx, N, H, W, C, R, PH, PW, bin_stride, spatial_scale,
+                                  sampling_ratio, ws, ws ? INT64_MAX : 0, stream);
+}
+
+extern "C" int mrcnn_roi_align_bwd_ws(const float *gy, const float *rois, float *gx, int N, int H,
+                                      int W, int C, int R, int PH, int PW, int bin_stride,
+                                      float spatial_scale, int sampling_ratio, void *ws,
+                                      int64_t ws_bytes, void *stream)
+{
     if (int rc = check_args(gy, rois, gx, N, H, W, C, R, PH, PW, sampling_ratio)) return rc;
     MRCNN_REQUIRE(bin_stride >= 1, "roi_align: bin_stride must be >= 1");
+    MRCNN_REQUIRE(ws == nullptr || ws_bytes >= mrcnn_roi_align_bwd_workspace_bytes(N, H, W, R, PH, PW, bin_stride),
+                  "roi_align_bwd: workspace smaller than mrcnn_roi_align_bwd_workspace_bytes(N, H, W, R, PH, PW, bin_stride)");
     hipStream_t s = mrcnn::as_stream(stream);
     MRCNN_REQUIRE(gx != nullptr, "roi_align_bwd: null gx");
     const int OH = (PH + bin_stride - 1) / bin_stride, OW = (PW + bin_stride - 1) / bin_stride;

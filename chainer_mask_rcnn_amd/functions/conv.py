@@ -85,7 +85,9 @@ class SparseRows(object):
     """Positions of a (N, H, W) map outside which the gradient arriving at a convolution's output
     is EXACTLY zero: ``rows`` int32 device tensor of sorted indices into N*H*W, ``lookup`` int32
     device tensor (N*H*W) position -> index into rows or -1, ``n`` = len(rows) (host int).
-    One-shot: the backward that uses it clears it; a fresh forward clears it as well."""
+    One-shot and owned by ONE forward: the producer makes a new object per forward (the conv node
+    records it), the backward that uses it clears it.  ``valid_for`` is the backward's guard: a hint
+    whose tables do not describe the node's own (N, H, W) map is ignored (dense backward)."""
 
     def __init__(self):
         self.clear()
@@ -96,6 +98,17 @@ class SparseRows(object):
 
     def set(self, rows, lookup, n):
         self.rows, self.lookup, self.n = rows, lookup, int(n)
+
+    def valid_for(self, d, device):
+        """True when the tables can drive the row-sparse backward of a convolution with output
+        map (d.N, d.P, d.Q) on ``device`` (shape / dtype / device checks only: no read-back)."""
+        r, l = self.rows, self.lookup
+        if r is None or l is None or self.n <= 0:
+            return False
+        size = d.N * d.P * d.Q
+        return (r.dtype == torch.int32 and l.dtype == torch.int32 and r.device == device and
+                l.device == device and r.is_contiguous() and l.is_contiguous() and
+                r.numel() == self.n and self.n <= size and l.numel() == size)
 
     @staticmethod
     def host_tables(positions, size):
@@ -210,7 +223,7 @@ class _Conv2dFn(torch.autograd.Function):
         M = d.N * d.P * d.Q
         gx = gW = gb = None
         hint = ctx.sparse_hint
-        if hint is not None and hint.rows is not None and hint.n > 0 and SPARSE_CONV_BACKWARD:
+        if hint is not None and SPARSE_CONV_BACKWARD and hint.valid_for(d, gy.device):
             gx, gW, gb = _sparse3x3_backward(ctx, d, x, Wc, g, hint, need_x, need_w, need_b)
             hint.clear()
             return gx, gW, gb, None, None, None, None, None, None
@@ -554,6 +567,27 @@ def weights_changed():
     _wino_u_cache.clear()
 
 
+# The cache has no cross-stream ordering: an entry is produced and read on the caller's current
+# stream and freed by ``weights_changed`` (every SGD step).  Work queued on a SIDE stream (the
+# frozen-prefix prefetch of models/resnet_extractor.py) therefore bypasses it.
+_WINO_CACHE_BYPASS = 0
+
+
+class no_filter_cache(object):
+    """``with no_filter_cache(): ...`` — Winograd convolutions inside transform their filter per call
+    instead of reading / filling the per-parameter cache (for work on a stream other than the one
+    the cache's entries live on)."""
+
+    def __enter__(self):
+        global _WINO_CACHE_BYPASS
+        _WINO_CACHE_BYPASS += 1
+
+    def __exit__(self, *exc):
+        global _WINO_CACHE_BYPASS
+        _WINO_CACHE_BYPASS -= 1
+        return False
+
+
 def _cached_filter_transform(W, Wc, d):
     key = id(W)
     hit = _wino_u_cache.get(key)
@@ -582,7 +616,8 @@ def wino_fwd(x, Wc, d, scale, shift, relu, keep_v=False, cache_for=None, exact_s
     if keep_v:
         v = torch.empty((_lib.load().mrcnn_conv3x3_wino_v_bytes(ctx_desc(d)) // 4,),
                         dtype=torch.float32, device=x.device)
-    u = _cached_filter_transform(cache_for, Wc, d) if cache_for is not None else None
+    u = _cached_filter_transform(cache_for, Wc, d) \
+        if cache_for is not None and not _WINO_CACHE_BYPASS else None
     _lib.call('mrcnn_conv3x3_wino_fwd', ctx_desc(d), _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(u),
               _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y), flags, _lib.ptr(v),
               _lib.ptr(_wino_ws(d, x.device)), _lib.stream_ptr())

@@ -33,6 +33,10 @@ class _ROIAlign2DFn(torch.autograd.Function):
                     and tuple(order.shape) == (R,)):
                 raise TypeError('roi_align_2d: order must be a contiguous int32 device tensor of '
                                 'shape (R,) — a permutation of the RoI rows')
+            if VALIDATE_ORDER and R > 0 and not torch.equal(
+                    torch.sort(order.long())[0], torch.arange(R, device=order.device)):
+                raise ValueError('roi_align_2d: order is not a permutation of 0..R-1 (a duplicate '
+                                 'leaves output rows unwritten, an out-of-range value reads past rois)')
         _lib.call('mrcnn_roi_align_fwd_ex', _lib.ptr(x), _lib.ptr(rois), _lib.ptr(y),
                   N, H, W, C, R, outh, outw, bin_stride, spatial_scale, sampling_ratio,
                   _lib.ptr(order) if order is not None and R > 0 else None, _lib.stream_ptr())
@@ -53,9 +57,10 @@ class _ROIAlign2DFn(torch.autograd.Function):
         ws = _lib.workspace(_lib.load().mrcnn_roi_align_bwd_workspace_bytes(
             N, H, W, R, outh, outw, bin_stride), gy.device,
                             'roi_align_bwd') if DETERMINISTIC_BACKWARD else None
-        _lib.call('mrcnn_roi_align_bwd_ex', _lib.ptr(gy), _lib.ptr(rois), _lib.ptr(gx),
+        _lib.call('mrcnn_roi_align_bwd_ws', _lib.ptr(gy), _lib.ptr(rois), _lib.ptr(gx),
                   N, H, W, C, R, outh, outw, bin_stride, spatial_scale,
-                  sampling_ratio, _lib.ptr(ws), _lib.stream_ptr())
+                  sampling_ratio, _lib.ptr(ws),
+                  int(ws.numel() * ws.element_size()) if ws is not None else 0, _lib.stream_ptr())
         # no gradient w.r.t. rois (roi_align_2d.py:389, :524)
         return gx, None, None, None, None, None, None, None
 

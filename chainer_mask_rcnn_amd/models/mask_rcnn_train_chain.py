@@ -30,18 +30,61 @@ def copy_stream(dev):
     return _COPY_STREAMS[key]
 
 
+_NP_OF = {torch.float32: np.float32, torch.int32: np.int32, torch.int64: np.int64,
+          torch.uint8: np.uint8}
+
+
+class _PinnedRing(object):
+    """Pinned host staging buffers for ``_upload``: a buffer is reused once the copy that read it
+    has completed (its event), so the host never waits for a copy and never for the copy stream's
+    other work (the input pipeline's next-batch upload shares that stream)."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.free = []           # [(buffer, event of its last copy or None)]
+
+    def take(self, nbytes):
+        with self.lock:
+            for i, (buf, ev) in enumerate(self.free):
+                if buf.numel() >= nbytes and (ev is None or ev.query()):
+                    return self.free.pop(i)[0]
+        return torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8).pin_memory()
+
+    def give(self, buf, ev):
+        with self.lock:
+            self.free.append((buf, ev))
+            if len(self.free) > 16:      # drop the smallest finished one
+                done = [i for i, (b, e) in enumerate(self.free) if e is None or e.query()]
+                if done:
+                    self.free.pop(min(done, key=lambda i: self.free[i][0].numel()))
+
+
+_PINNED = _PinnedRing()
+
+
 def _upload(array, dtype, dev):
-    """Host array -> device tensor through a side stream.  A pageable host-to-device copy
-    issued on the compute stream blocks the host until everything queued there (e.g. the whole
-    head forward) has run; on its own stream it only waits for the copy itself, so the host
-    keeps preparing targets while the GPU computes.  The compute stream is ordered after it."""
+    """Host array -> device tensor: staged in pinned memory and copied asynchronously on the copy
+    stream; the compute stream is ordered after an EVENT recorded right behind this copy — not
+    after the whole copy stream, which also carries the input pipeline's next-batch upload and
+    its prepare kernels (tools/train_loop.py) — and the host does not wait at all."""
     if dev.type != 'cuda':
         return torch.tensor(array, dtype=dtype, device=dev)
+    a = np.ascontiguousarray(array, dtype=_NP_OF[dtype])
     side = copy_stream(dev)
     main = torch.cuda.current_stream(dev)
+    n = a.nbytes
     with torch.cuda.stream(side):
-        t = torch.tensor(array, dtype=dtype, device=dev)
-    main.wait_stream(side)
+        t = torch.empty(a.shape, dtype=dtype, device=dev)
+        if n > 0:
+            stage = _PINNED.take(n)
+            stage[:n].numpy()[:] = a.reshape(-1).view(np.uint8)
+            t.view(-1).view(torch.uint8).copy_(stage[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    if n > 0:
+        _PINNED.give(stage, ev)
+    main.wait_event(ev)
     t.record_stream(main)
     return t
 
@@ -52,9 +95,6 @@ def _pool():
         from concurrent.futures import ThreadPoolExecutor
         _POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix='mrcnn-targets')
     return _POOL
-
-
-_NP_OF = {torch.float32: np.float32, torch.int32: np.int32, torch.int64: np.int64}
 
 
 def _upload_many(arrays, dtypes, dev):

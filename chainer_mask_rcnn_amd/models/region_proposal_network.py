@@ -52,9 +52,10 @@ class RegionProposalNetwork(torch.nn.Module):
         self._anchor_cache = {}
         # map positions outside which the gradient of conv1's output is exactly zero (the sampled
         # anchors of the RPN losses): filled by MaskRCNNTrainChain where the anchor targets are
-        # built, consumed by conv1's backward (functions/conv.py: SparseRows)
-        from ..functions.conv import SparseRows
-        self.grad_rows = SparseRows()
+        # built, consumed by conv1's backward (functions/conv.py: SparseRows).  A NEW object per
+        # forward: each graph's conv1 node keeps the hint of ITS forward, so two forwards before a
+        # backward (gradient accumulation) never see each other's rows
+        self.grad_rows = None
 
     def _anchor(self, hh, ww, device):
         key = (hh, ww, str(device))
@@ -69,8 +70,8 @@ class RegionProposalNetwork(torch.nn.Module):
         n, _, hh, ww = x.shape
         A = self.n_anchor
         _, anchor = self._anchor(hh, ww, x.device)
-        from ..functions.conv import sparse_output_grad
-        self.grad_rows.clear()
+        from ..functions.conv import SparseRows, sparse_output_grad
+        self.grad_rows = SparseRows()
         with sparse_output_grad(self.grad_rows):
             h = self.conv1(x, relu=True)
         out = self.loc_score(h)                               # (N, 5A(+pad), H, W), NHWC

@@ -211,10 +211,11 @@ class ResNetExtractorBase(torch.nn.Module):
         # stream of its own: a fifth stream changes which HIP streams share a hardware queue
         # (GPU_MAX_HW_QUEUES = 4) and the proposal chain then queues behind the deferred weight
         # gradients — measured +2.4 ms under data parallelism, +6 ms with 5..8 queues
-        from ..functions.conv import defer_stream
+        from ..functions.conv import defer_stream, no_filter_cache
         side, main = defer_stream(dev), torch.cuda.current_stream(dev)
         side.wait_stream(main)
-        with torch.cuda.stream(side):
+        # (the transformed-filter cache is ordered on the main stream only: bypassed here)
+        with torch.cuda.stream(side), no_filter_cache():
             h = self._frozen_prefix(x)
             ready = torch.cuda.Event()
             ready.record(side)
@@ -239,8 +240,16 @@ class ResNetExtractorBase(torch.nn.Module):
             skip_until, frozen = self.freeze_at, False
         for key, funcs in self.functions.items():
             if skip_until is not None:
+                # a stage the prefetch already ran: nothing to compute; its hook has nothing to
+                # fire on (no gradient below freeze_at), but target_layer still ends the walk —
+                # possible only when it IS the last prefetched stage, whose output h holds
                 if key == skip_until:
                     skip_until = None
+                    if key == self.target_layer:
+                        break
+                else:
+                    assert key != self.target_layer, \
+                        'target_layer %r lies inside the prefetched frozen prefix' % (key,)
                 continue
             for func in funcs:
                 if frozen:

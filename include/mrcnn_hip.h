@@ -95,6 +95,14 @@ int64_t mrcnn_roi_align_bwd_workspace_bytes(int N, int H, int W, int R, int PH, 
 int mrcnn_roi_align_bwd_ex(const float *gy, const float *rois, float *gx,
                            int N, int H, int W, int C, int R, int PH, int PW, int bin_stride,
                            float spatial_scale, int sampling_ratio, void *ws, void *stream);
+/* Same call with the workspace's extent: fails (returns non-zero, mrcnn_last_error) when ws is
+ * non-NULL and ws_bytes < mrcnn_roi_align_bwd_workspace_bytes(N, H, W, R, PH, PW, bin_stride) — a
+ * caller that sized ws by an older formula gets an error instead of a table write past its buffer.
+ * mrcnn_roi_align_bwd_ex is this call with the extent taken on trust. */
+int mrcnn_roi_align_bwd_ws(const float *gy, const float *rois, float *gx,
+                           int N, int H, int W, int C, int R, int PH, int PW, int bin_stride,
+                           float spatial_scale, int sampling_ratio, void *ws, int64_t ws_bytes,
+                           void *stream);
 
 /* ---- row-sparse backward of a 3x3 / stride 1 / pad 1 convolution --------------------------
  * The reference back-propagates the RPN losses through conv1 of

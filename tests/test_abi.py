@@ -141,3 +141,31 @@ def test_roi_spatial_order_is_a_permutation_grouped_by_image_and_band():
     keys = [(int(idx[i]), int(np.floor(yc[i] / 6.0)), float(xc[i])) for i in o]
     assert keys == sorted(keys)
     assert functions.roi_spatial_order(np.zeros((0, 4), np.float32), np.zeros((0,), np.int32), 1 / 16.).shape == (0,)
+
+
+def test_mrcnn_tune_failure_is_sticky():
+    """MRCNN_TUNE: every entry is parsed before any is applied, and a knob the library rejects makes
+    every later load() raise the same error (the process-wide library state is half-tuned) instead
+    of silently handing out the library on the second call."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from chainer_mask_rcnn_amd import _lib\n"
+        "msgs = []\n"
+        "for _ in range(2):\n"
+        "    try:\n"
+        "        _lib.load(); msgs.append('loaded')\n"
+        "    except _lib.MrcnnHipError as e:\n"
+        "        msgs.append(str(e))\n"
+        "assert msgs[0] == msgs[1] and 'MRCNN_TUNE' in msgs[0], msgs\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tune in ('fused_tail=512,no_such_knob=1', 'fused_tail', '=3'):
+        env = dict(os.environ, MRCNN_TUNE=tune)
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip() == 'ok', (tune, out.stdout, out.stderr)
+    env = dict(os.environ, MRCNN_TUNE='fused_tail=512')
+    ok = subprocess.run([sys.executable, '-c', code.replace("'MRCNN_TUNE' in msgs[0]", "msgs[0] == 'loaded'")],
+                        env=env, capture_output=True, text=True)
+    assert ok.returncode == 0, (ok.stdout, ok.stderr)

@@ -255,6 +255,67 @@ def test_row_sparse_3x3_backward_equals_dense(dev, shape):
         assert float((a - s_).abs().max()) <= 1e-4 * scale
 
 
+def test_row_sparse_hint_is_per_forward(dev):
+    """Two forwards of the RPN before either backward (gradient accumulation): each graph's conv1
+    node keeps the hint of ITS forward, so the first graph's row-sparse backward never sees the
+    second batch's rows; and a hint whose tables describe another map size is ignored (dense
+    backward) instead of driving the gather / scatter kernels out of bounds."""
+    from chainer_mask_rcnn_amd.functions import conv as conv_mod
+    from chainer_mask_rcnn_amd.models.region_proposal_network import RegionProposalNetwork
+    torch.manual_seed(3)
+    rpn = RegionProposalNetwork(32, 32, anchor_scales=[4, 8], feat_stride=16,
+                                proposal_creator_params=dict(n_train_pre_nms=200, n_train_post_nms=50,
+                                                             min_size=0)).to(dev)
+    rpn.train()
+    N, H, W, A = 1, 12, 14, rpn.n_anchor
+    xs = [torch.randn((N, 32, H, W), device=dev).contiguous(memory_format=torch.channels_last)
+          for _ in range(2)]
+    pos = [np.array([3, 17, 40, 99]), np.array([0, 5, 120, 167])]
+
+    def loss_of(scores, p):
+        # a loss that reads the scores of the anchors at positions p only
+        idx = torch.tensor((p[:, None] * A + np.arange(A)[None]).ravel(), device=dev)
+        return (scores.reshape(-1)[idx] ** 2).sum()
+
+    def run(sparse):
+        rpn.zero_grad(set_to_none=True)
+        outs, hints = [], []
+        for x in xs:
+            outs.append(rpn(x, (H * 16, W * 16), [1.0])[1])
+            hints.append(rpn.grad_rows)
+        assert hints[0] is not hints[1]
+        if sparse:
+            for h, p in zip(hints, pos):
+                r, l = conv_mod.SparseRows.host_tables(p, N * H * W)
+                h.set(torch.tensor(r, device=dev), torch.tensor(l, device=dev), len(r))
+        losses = [loss_of(s_, p) for s_, p in zip(outs, pos)]
+        losses[0].backward()            # AFTER the second forward
+        g0 = rpn.conv1.W.grad.clone()
+        losses[1].backward()
+        assert all(h.rows is None for h in hints)
+        return g0, rpn.conv1.W.grad.clone()
+
+    dense, sparse = run(False), run(True)
+    for a, s_ in zip(dense, sparse):
+        scale = float(a.abs().max())
+        assert scale > 0
+        assert float((a - s_).abs().max()) <= 1e-4 * scale
+
+    # a hint for a different map: rejected by the backward's guard, result = dense
+    xt = xs[0].clone().requires_grad_(True)
+    hint = conv_mod.SparseRows()
+    with conv_mod.sparse_output_grad(hint):
+        y = F.conv2d(xt, rpn.conv1.W, rpn.conv1.b, 1, 1, relu=True)
+    r, l = conv_mod.SparseRows.host_tables(np.array([1, 2]), N * H * W + 7)
+    hint.set(torch.tensor(r, device=dev), torch.tensor(l, device=dev), len(r))
+    assert not hint.valid_for(conv_mod.make_desc(xt.shape, rpn.conv1.W.shape, 1, 1), xt.device)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd = xs[0].clone().requires_grad_(True)
+    F.conv2d(xd, rpn.conv1.W, rpn.conv1.b, 1, 1, relu=True).backward(gy)
+    assert torch.equal(xt.grad, xd.grad)
+
+
 def test_conv_linearity_at_full_size(dev):
     """Size-independent property at the BASELINE C2 res5 shape (1024 RoIs):
     conv(a*x1 + x2) == a*conv(x1) + conv(x2) to fp32 round-off, plus a spot check
