@@ -33,8 +33,8 @@ sys.path.insert(0, ROOT)
 
 MEAN = (123.152, 115.903, 103.063)        # models/mask_rcnn_resnet.py:42
 FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-# opt-in split-operand kernels (--tune split_bf16=...): six dense-bf16 MFMAs (2500 TFLOP/s) per
-# fp32-equivalent multiply-add
+# split-operand kernels (the default arithmetic): six dense-bf16 MFMAs
+# (2500 TFLOP/s) per fp32-equivalent multiply-add
 SPLIT_MFMA_PEAK_TFLOPS = round(2500.0 / 6.0, 1)
 HBM_PEAK_GBS = 8000.0
 # Algorithmic work of one train step per image: fwd 1076.6 GFLOP,
@@ -199,7 +199,7 @@ def roi_align_isolated(chain, device, reps=20):
             for k, v in prof.items() if k.startswith('roi_align')}
 
 
-def pmc_traffic(kernel_name):
+def pmc_traffic(kernel_name, split=False):
     """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary
     (profiles/*_pmc_fetch_write.json: separate FETCH_SIZE and WRITE_SIZE passes over this
     same command; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM: gfx950
@@ -213,16 +213,18 @@ def pmc_traffic(kernel_name):
     if not m:
         return None
     mode = {'FWD': 0, 'DGRAD': 1, 'WGRAD': 2}[m.group(3)]
-    # profiler kinds follow the kernel symbols; the unmasked variant (<.., false, false>) is
-    # what the train step runs
-    key = 'conv_gemm_kernel<%s, %s, %d, false' % (m.group(1), m.group(2), mode)
-    with open(files[-1]) as f:
-        data = json.load(f)
-    for k, v in data.items():
-        if key in k and v.get('WRITE_SIZE_KB_per_launch') is not None:
-            return dict(bytes_per_launch=round((2.0 * v['FETCH_SIZE_KB_per_launch'] +
-                                                v['WRITE_SIZE_KB_per_launch']) * 1024.0),
-                        source=os.path.basename(files[-1]))
+    # profiler kinds follow the kernel symbols; the unmasked variant (<.., false, false, SPLIT..>)
+    # is what the train step runs
+    key = 'conv_gemm_kernel<%s, %s, %d, false, false, %s' % (m.group(1), m.group(2), mode,
+                                                             'true' if split else 'false')
+    for path in reversed(files):          # newest summary that holds this symbol
+        with open(path) as f:
+            data = json.load(f)
+        for k, v in data.items():
+            if key in k and v.get('WRITE_SIZE_KB_per_launch') is not None:
+                return dict(bytes_per_launch=round((2.0 * v['FETCH_SIZE_KB_per_launch'] +
+                                                    v['WRITE_SIZE_KB_per_launch']) * 1024.0),
+                            source=os.path.basename(path))
     return None
 
 
@@ -417,8 +419,9 @@ def main():
     ap.add_argument('--defer-wgrad', type=int, default=5,
                     help='number of res5 weight gradients (a.conv2, a.conv1, a.conv3, a.conv4, b1.conv2, ...) held back into the '
                          "next step's proposal window (single-GPU runs; 0 = off)")
-    ap.add_argument('--no-split-bf16', dest='split_bf16', action='store_false',
-                    help='skip the extra measurement on the opt-in split-operand (3 x bf16) GEMM kernels')
+    ap.add_argument('--no-fp32-mfma', '--no-split-bf16', dest='fp32_mfma', action='store_false',
+                    help='skip the extra measurement on the fp32-MFMA GEMM kernels (the default arithmetic '
+                         'up to round 3)')
     ap.add_argument('--tune', default='',
                     help='developer: comma-separated mrcnn_set_tuning knobs, e.g. small_m_split=4')
     ap.add_argument('--bucket-mb', type=float, default=16.0,
@@ -651,30 +654,45 @@ def main():
                                  'F(4x4,3x3) route (the default up to round 2; DESIGN.md section 4.3)',
                         loss=round(float(loss_w.item()), 5))
 
-    # ---- the same step on the opt-in split-operand GEMM kernels ----------
-    split_run = None
-    if args.split_bf16:
-        from chainer_mask_rcnn_amd.functions import conv as conv_mod
-        conv_mod.set_gemm_arithmetic('split_bf16x3')
+    # ---- the same step on the fp32-MFMA GEMM kernels (the default up to round 3) ------------------
+    fp32_run = None
+    from chainer_mask_rcnn_amd.functions import conv as conv_mod
+    main_arithmetic = conv_mod.GEMM_ARITHMETIC
+    if any(kv.split('=')[0] == 'split_bf16' for kv in args.tune.split(',') if '=' in kv):
+        main_arithmetic = 'split_bf16x3' if any(
+            kv.split('=')[0] == 'split_bf16' and int(kv.split('=')[1]) != 0
+            for kv in args.tune.split(',') if '=' in kv) else 'fp32'
+    if args.fp32_mfma and main_arithmetic != 'fp32':
+        conv_mod.set_gemm_arithmetic('fp32')
         try:
             for _ in range(max(2, args.warmup)):
                 step()
             fence()
+            lib.mrcnn_profile_enable(2) if not args.no_profile else None
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 loss_s = step()
             fence()
             el_s = max_over_ranks(time.perf_counter() - t0)
+            prof_f = {} if args.no_profile else profile_summary()
+            lib.mrcnn_profile_enable(0)
         finally:
-            conv_mod.set_gemm_arithmetic('fp32')
-        split_run = dict(value=round(args.steps * args.batch * world / el_s, 3), unit='images/sec',
-                         ms_per_step=round(el_s / args.steps * 1e3, 3),
-                         workload="same step, functions.conv.set_gemm_arithmetic('split_bf16x3'): the "
-                                  'forward-form and 128x128 weight-gradient GEMMs stage every fp32 operand '
-                                  'as three exact bf16 planes and run six bf16 MFMAs per K step with fp32 '
-                                  'accumulation (error against float64 at the fp32 kernel\'s level, '
-                                  'tests/test_gpu_split_bf16.py); opt-in, NOT the headline value',
-                         loss=round(float(loss_s.item()), 5))
+            conv_mod.set_gemm_arithmetic(conv_mod.DEFAULT_GEMM_ARITHMETIC)
+        fp32_run = dict(value=round(args.steps * args.batch * world / el_s, 3), unit='images/sec',
+                        ms_per_step=round(el_s / args.steps * 1e3, 3),
+                        workload="same step, functions.conv.set_gemm_arithmetic('fp32'): every GEMM on "
+                                 'v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s peak), the default arithmetic up '
+                                 'to round 3',
+                        loss=round(float(loss_s.item()), 5))
+        conv_f = {k: v for k, v in prof_f.items() if k.startswith('conv_gemm') and v['total_ms'] > 0}
+        if conv_f:
+            name_f = max(conv_f, key=lambda k: conv_f[k]['total_ms'])
+            ach_f = conv_f[name_f]['flops'] / (conv_f[name_f]['total_ms'] * 1e-3) / 1e12
+            fp32_run['roofline'] = dict(bound='mfma', kernel=name_f, achieved=round(ach_f, 2),
+                                        peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                                        frac=round(ach_f / FP32_MFMA_PEAK_TFLOPS, 4),
+                                        avg_launch_us=round(conv_f[name_f]['total_ms'] * 1e3 /
+                                                            conv_f[name_f]['launches'], 2))
 
     # ---- third measurement: the same step fed by the train loop's input pipeline ----------------
     pipeline = None
@@ -726,13 +744,12 @@ def main():
             name = max(conv, key=lambda k: conv[k]['total_ms'])
             d = conv[name]
             ach = d['flops'] / (d['total_ms'] * 1e-3) / 1e12
-            split_tuned = any(kv.split('=')[0] == 'split_bf16' and int(kv.split('=')[1]) != 0
-                              for kv in args.tune.split(',') if '=' in kv)
+            split_tuned = main_arithmetic == 'split_bf16x3'
             peak = SPLIT_MFMA_PEAK_TFLOPS if split_tuned else FP32_MFMA_PEAK_TFLOPS
             roofline = dict(bound='mfma', kernel=name, achieved=round(ach, 2),
                             peak=peak, unit='TFLOP/s',
                             frac=round(ach / peak, 4),
-                            traffic=None if split_tuned else pmc_traffic(name),
+                            traffic=pmc_traffic(name, split_tuned),
                             # whole step: flops the GEMM kernels executed / step wall time / peak
                             step_frac=round(gemm_gflop / 1e3 / elapsed / peak, 4),
                             flops_counting='nominal per launch: 2*M*N*K with K = R*S*C_in (padding taps '
@@ -794,8 +811,10 @@ def main():
             data='synthetic', config=config, roofline=roofline)
         if roofline is not None and roofline['peak'] != FP32_MFMA_PEAK_TFLOPS:
             out['dtype'] = 'f32 (operands split into 3 x bf16, six bf16 MFMAs per K step, f32 accumulate)'
-            roofline['peak_note'] = ('developer run on the opt-in split-operand kernels: peak = dense bf16 '
-                                     'MFMA 2500 TFLOP/s / 6 products; flops are nominal fp32 flops')
+            roofline['peak_note'] = ('split-operand arithmetic: peak = dense bf16 MFMA 2500 TFLOP/s / 6 '
+                                     'products per fp32 multiply-add; achieved = nominal fp32 flops / '
+                                     'kernel time (the matrix pipe executes 6x as many bf16 flops: '
+                                     '%.0f of 2500 TFLOP/s)' % (6 * ach))
         if rotating is not None:
             out['rotating_h2d'] = rotating
         if pipeline is not None:
@@ -806,8 +825,8 @@ def main():
             out['device_targets'] = dev_targets
         if wino_fwd is not None:
             out['direct_head_forward'] = wino_fwd
-        if split_run is not None:
-            out['split_bf16x3'] = split_run
+        if fp32_run is not None:
+            out['fp32_mfma'] = fp32_run
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         emit_json(out)

@@ -84,6 +84,9 @@ constexpr int min_blocks(int tm, int mode, bool masked)
 #define MRCNN_WGRAD_INKERNEL_REDUCE 0
 #endif
 constexpr int64_t kWgradCounterBytes = 1 << 20;   // >= 4 B x tiles for any supported filter
+#ifndef MRCNN_SPLIT_ILV          // SPLIT forward form: next slice's loads between the MFMAs (see ILV)
+#define MRCNN_SPLIT_ILV 1
+#endif
 #ifndef MRCNN_GEMM_WIDE_EPILOGUE
 #define MRCNN_GEMM_WIDE_EPILOGUE 1
 #endif
@@ -166,7 +169,28 @@ struct GemmParams {
     // (b / 256) x stagger_cycles shader cycles before its first load, so the phases interleave.
     // Placement only decides how well this works, never the result.
     int stagger_slots, stagger_cycles;
+    // Pre-split operands (SPLIT forward-form kernels, see "operand planes" below): the three bf16
+    // planes of A / B as written by their producer, and the planes of the output this launch is
+    // to write beside C (any of them NULL: the fp32 tensor is split while it is staged / nothing
+    // is written).  Extents in bytes (< 2 GiB: kOOB must stay out of range).
+    const unsigned short *A_pl, *B_pl;
+    unsigned short *C_pl;
+    unsigned apl_bytes, bpl_bytes, cpl_bytes;
 };
+
+// ---- operand planes -----------------------------------------------------------------------
+// A [rows][L] fp32 matrix whose row length L is a multiple of 32 has a PLANE image of 6 bytes per
+// element: per row, per 32-element chunk, 3 x 32 bf16 = hi | mid | lo (64 bytes each) with
+// x = hi + mid + lo exactly (split3).  A K slice of a row is one contiguous 192-byte run.  The
+// forward-form SPLIT kernels stage such an operand with plain 16-byte copies — the conversion,
+// which otherwise runs once per output-tile column (A) or row (B) that re-reads the element, is
+// done once, by whoever produced the tensor (GEMM epilogue, Winograd transforms, ROIAlign,
+// mrcnn_split_planes).  Results are bit-identical to the in-kernel split.
+constexpr int kPlaneChunkBytes = 192;
+__host__ __device__ __forceinline__ unsigned plane_off(unsigned row_bytes6, unsigned row, unsigned col, unsigned q)
+{
+    return row * row_bytes6 + (col >> 5) * kPlaneChunkBytes + q * 64u + (col & 31u) * 2u;
+}
 
 #ifdef MRCNN_GEMM_TRACE
 __device__ unsigned long long g_trace[64 * 4 * 64 * 5];
@@ -225,6 +249,13 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
                        __uint_as_float(v.w));
 }
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+#ifdef MRCNN_DBG_NOLOAD
+    off = kOOB;
+#endif
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off)
 {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
@@ -245,6 +276,13 @@ __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned off, 
     off = kOOB;
 #endif
     __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, MRCNN_GEMM_STORE_AUX);
+}
+__device__ __forceinline__ void bstore8(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned a, unsigned b)
+{
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 u;
+    u.x = a; u.y = b;
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
 }
 __device__ __forceinline__ float4 relu_mask(float4 v, float4 y)
 {
@@ -312,11 +350,29 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &
 // error of one fp32 multiply-add, so results stay fp32-accurate (tests/test_gpu_split_bf16.py
 // measures the error against float64 next to the fp32 MFMA kernel's), while the matrix pipe
 // does 6 x 32 instead of 8 x 64 cycles per 32x32x16 block.
-template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false>
+// G groups of (MFMAs, one global load, LDS reads) covering NM MFMAs and ND LDS reads in total
+template <int G, int NM, int ND, int I = 0>
+__device__ __forceinline__ void sgb_interleave()
+{
+    if constexpr (I < G) {
+        constexpr int m = NM * (I + 1) / G - NM * I / G, d = ND * (I + 1) / G - ND * I / G;
+        if constexpr (m > 0) __builtin_amdgcn_sched_group_barrier(0x008, m, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if constexpr (d > 0) __builtin_amdgcn_sched_group_barrier(0x100, d, 0);
+        sgb_interleave<G, NM, ND, I + 1>();
+    }
+}
+
+// PL (SPLIT forward form only): bit 0 = the A operand, bit 1 = the B operand arrive as planes.
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false, int PL = 0>
 __global__ void __launch_bounds__(256, SPLIT ? (TM == 2 ? 2 : 4) : min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
+    static_assert(PL == 0 || (SPLIT && MODE == FWD && !(MASKED && (PL & 1))),
+                  "operand planes: SPLIT forward form; a masked A operand is split in the kernel");
+    constexpr bool A_PL = (PL & 1) != 0, B_PL = (PL & 2) != 0;
+    constexpr bool ILV = MRCNN_SPLIT_ILV != 0 && SPLIT && MODE == FWD && !MASKED;
     static_assert(!SPLIT || (BK == 32 && TM == TN &&
                              ((MODE == FWD && (TM == 1 || TM == 2)) || (MODE == WGRAD && !WPERM && TM == 2))),
                   "SPLIT: forward form (128x128, 64x64) / weight gradient (128x128) only");
@@ -369,6 +425,9 @@ conv_gemm_kernel(const GemmParams p)
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + zb * p.batch_a, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B + zb * p.batch_b, p.b_bytes);
     const __amdgpu_buffer_rsrc_t rMask = make_rsrc(p.mask_y, p.a_bytes);
+    // plane images: 3 ushorts per element, batched problems 3 * batch_x ushorts apart
+    const __amdgpu_buffer_rsrc_t rApl = make_rsrc(A_PL ? p.A_pl + zb * p.batch_a * 3 : nullptr, p.apl_bytes);
+    const __amdgpu_buffer_rsrc_t rBpl = make_rsrc(B_PL ? p.B_pl + zb * p.batch_b * 3 : nullptr, p.bpl_bytes);
     const bool use_mask = HAS_MASK && p.mask_y != nullptr;
 
     // tile -> (m0, n0).  Workgroup b runs on XCD b % 8 (observed dispatch order); remap so
@@ -400,7 +459,20 @@ conv_gemm_kernel(const GemmParams p)
     // ---------------- per-thread gather state -----------------------------------
     constexpr int KC_C4 = BK / 4, KC_RPP = 256 / KC_C4;   // float4 per row, rows per pass
     const int kc_row = tid / KC_C4, kc_c4 = tid % KC_C4;
-    int a_n[AV], a_y[AV], a_x[AV];     // FWD/DGRAD: pixel coords of each A row
+    // plane operands: a tile's K slice is BM (BN) runs of 192 bytes = 12 pieces of 16 bytes; piece
+    // (tid + 256 i) of the tile -> row (tid + 256 i) / 12, piece pc of its run (plane pc >> 2,
+    // 16-byte slot pc & 3): consecutive lanes read consecutive pieces
+    constexpr int NPA = A_PL ? BM * 12 / 256 : 1, NPB = B_PL ? BN * 12 / 256 : 1;
+    constexpr int NA = A_PL ? NPA : AV;                 // A rows a thread addresses
+    auto pl_row = [&](int i) { return (tid + 256 * i) / 12; };
+    auto pl_pc = [&](int i) { return (tid + 256 * i) % 12; };
+    auto a_row = [&](int i) { return A_PL ? pl_row(i) : kc_row + KC_RPP * i; };
+    // LDS position (ushort index inside an operand's three planes) of plane piece i
+    auto pl_lds = [&](int i, int plane_len) {
+        const int row = pl_row(i), pc = pl_pc(i);
+        return (pc >> 2) * plane_len + row * SROW + (((pc & 3) ^ ((row >> 2) & 3)) << 3);
+    };
+    int a_n[NA], a_y[NA], a_x[NA];     // FWD/DGRAD: pixel coords of each A row
     // 1x1 / stride 1 / pad 0 forward-form launches (two thirds of the RoI head's GEMMs): GEMM row
     // m IS pixel m of the gathered tensor — no (image, y, x) decomposition, i.e. none of the
     // eight integer divisions of the general set-up
@@ -408,16 +480,19 @@ conv_gemm_kernel(const GemmParams p)
                            p.perm_n == 0 && !p.stem && p.gp == p.sh && p.gq == p.sw;   // uniform
     if (MODE != WGRAD && pointwise) {
 #pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int m = m0 + kc_row + KC_RPP * i;
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + a_row(i);
             a_n[i] = m < p.M ? m : 0;          // (pixel index; folded into a_base below)
+#ifdef MRCNN_DBG_AMOD      // experiment: every tile reads the same few A rows (L2-resident operand)
+            a_n[i] &= MRCNN_DBG_AMOD - 1;
+#endif
             a_x[i] = 0;
             a_y[i] = m < p.M ? 0 : -(1 << 28);
         }
     } else if (MODE != WGRAD) {
 #pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int m = m0 + kc_row + KC_RPP * i;
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + a_row(i);
             const bool ok = m < p.M;
             const int mm = ok ? m : 0;
             int n, rem;
@@ -534,7 +609,8 @@ conv_gemm_kernel(const GemmParams p)
         }
     }
 
-    float4 ra[AV], rb[BV];
+    float4 ra[A_PL ? 1 : AV], rb[B_PL ? 1 : BV];
+    u32x4 pa_[NPA], pb_[NPB];                // plane pieces in flight (A_PL / B_PL)
     float4 rm[HAS_MASK ? AV : 1];
     float4 rscale = make_float4(1.f, 1.f, 1.f, 1.f);
     const bool use_scale = HAS_MASK && p.in_scale != nullptr;
@@ -544,17 +620,23 @@ conv_gemm_kernel(const GemmParams p)
     // Loop-invariant parts of every load address (element offsets; an invalid row carries the
     // sentinel 0x20000000 so that 4 * offset lands beyond num_records and reads as zero).
     constexpr unsigned kBad = 0x20000000u;
-    unsigned a_base[AV], b_base[BV];
+    // (plane operands: BYTE offsets of the thread's pieces, 6 bytes per element)
+    constexpr int NB = B_PL ? NPB : BV;
+    unsigned a_base[NA], b_base[NB];
     if (MODE != WGRAD) {
 #pragma unroll
-        for (int i = 0; i < AV; ++i)
-            a_base[i] = pointwise ? (unsigned)(a_n[i] * p.lda + kc_c4 * 4)
-                                  : (unsigned)(((a_n[i] * p.sh + a_y[i]) * p.sw + a_x[i]) * p.lda + kc_c4 * 4);
+        for (int i = 0; i < NA; ++i) {
+            const unsigned pix = pointwise ? (unsigned)a_n[i]
+                                           : (unsigned)((a_n[i] * p.sh + a_y[i]) * p.sw + a_x[i]);
+            a_base[i] = A_PL ? pix * (unsigned)(p.lda * 6) + (unsigned)(pl_pc(i) * 16)
+                             : pix * (unsigned)p.lda + (unsigned)(kc_c4 * 4);
+        }
         if (FWDLIKE) {
 #pragma unroll
-            for (int i = 0; i < BV; ++i) {
-                const int n = n0 + kc_row + KC_RPP * i;
-                b_base[i] = n < p.N ? (unsigned)(n * p.ldb + kc_c4 * 4) : kBad;
+            for (int i = 0; i < NB; ++i) {
+                const int n = n0 + (B_PL ? pl_row(i) : kc_row + KC_RPP * i);
+                if (B_PL) b_base[i] = n < p.N ? (unsigned)n * (unsigned)(p.ldb * 6) + (unsigned)(pl_pc(i) * 16) : kOOB;
+                else b_base[i] = n < p.N ? (unsigned)(n * p.ldb + kc_c4 * 4) : kBad;
             }
         } else {
 #pragma unroll
@@ -579,6 +661,42 @@ conv_gemm_kernel(const GemmParams p)
                         p.gp == p.sh && p.gq == p.sw;      // uniform
     const int RS = p.R * p.S;
 
+    // ILV (SPLIT forward form without mask staging): load_slice only computes the byte offsets of
+    // the slice's loads; the loads themselves are issued INSIDE the following compute(), spread
+    // between its MFMAs (issue_loads + the sched_group_barrier sequence there).  Issued as one
+    // burst ahead of the MFMAs, the 8 .. 12 16-byte loads of every wave of the CU queue behind
+    // each other in the texture path and the wave sits in their issue for 1000 - 1700 cycles
+    // (s_memtime stamps) before its first MFMA.
+    unsigned oa[ILV ? NA : 1], ob[ILV ? NB : 1];
+    auto ldA = [&](int i, unsigned off) {
+        if constexpr (ILV) {
+            oa[i] = off;
+        } else if constexpr (A_PL) {
+            pa_[i] = bload16(rApl, off);
+        } else {
+            ra[i] = bload4(rA, off);
+            if (HAS_MASK && use_mask) rm[i] = bload4(rMask, off);
+        }
+    };
+    auto ldB = [&](int i, unsigned off) {
+        if constexpr (ILV) ob[i] = off;
+        else if constexpr (B_PL) pb_[i] = bload16(rBpl, off);
+        else rb[i] = bload4(rB, off);
+    };
+    auto issue_loads = [&]() {
+        if constexpr (ILV) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if constexpr (A_PL) pa_[i] = bload16(rApl, oa[i]);
+                else ra[i] = bload4(rA, oa[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if constexpr (B_PL) pb_[i] = bload16(rBpl, ob[i]);
+                else rb[i] = bload4(rB, ob[i]);
+            }
+        }
+    };
     // issue the global loads of slice kt (nothing here consumes a loaded value).
     // FWD/DGRAD K order: channel chunk outer, filter tap (r,s) inner — consecutive slices re-read
     // the same 32-channel slab of neighbouring pixels, which stays in the CU's L1.
@@ -591,18 +709,25 @@ conv_gemm_kernel(const GemmParams p)
             const int c0 = (kt + kt0) * BK;
             const int cc = c0 + kc_c4 * 4;
             const bool c_ok = cc < p.Kc;
+            if constexpr (A_PL) {       // (planes: Kc is a multiple of BK, every slice is whole)
 #pragma unroll
-            for (int i = 0; i < AV; ++i) {
-                const unsigned off = (c_ok && a_y[i] == 0) ? 4u * (a_base[i] + (unsigned)c0) : kOOB;
-                ra[i] = bload4(rA, off);
-                if (HAS_MASK && use_mask) rm[i] = bload4(rMask, off);
+                for (int i = 0; i < NPA; ++i)
+                    ldA(i, a_y[i] == 0 ? a_base[i] + (unsigned)(c0 * 6) : kOOB);
+            } else {
+#pragma unroll
+                for (int i = 0; i < AV; ++i)
+                    ldA(i, (c_ok && a_y[i] == 0) ? 4u * (a_base[i] + (unsigned)c0) : kOOB);
             }
             if (HAS_MASK && use_scale)
                 rscale = c_ok ? *reinterpret_cast<const float4 *>(p.in_scale + cc)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (B_PL) {
 #pragma unroll
-            for (int i = 0; i < BV; ++i)
-                rb[i] = bload4(rB, c_ok ? 4u * (b_base[i] + (unsigned)c0) : kOOB);
+                for (int i = 0; i < NPB; ++i) ldB(i, b_base[i] + (unsigned)(c0 * 6));
+            } else {
+#pragma unroll
+                for (int i = 0; i < BV; ++i) ldB(i, c_ok ? 4u * (b_base[i] + (unsigned)c0) : kOOB);
+            }
             return;
         }
         if (FWDLIKE || MODE == DGRAD) {
@@ -622,23 +747,26 @@ conv_gemm_kernel(const GemmParams p)
             // wave-uniform part of the A address for this slice
             const int tap = (FWDLIKE ? (r * p.sw + s) : -(r * p.sw + s)) * p.lda + c0;
 #pragma unroll
-            for (int i = 0; i < AV; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 int iy, ix;
                 if (FWDLIKE) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? (cc >> 2) : 0); }
                 else { iy = a_y[i] - r; ix = a_x[i] - s; }
                 const bool ok = c_ok && (unsigned)iy < (unsigned)p.sh && (unsigned)ix < (unsigned)p.sw;
-                const unsigned off = ok ? 4u * (a_base[i] + (unsigned)tap) : kOOB;
-                ra[i] = bload4(rA, off);
-                if (HAS_MASK && use_mask) rm[i] = bload4(rMask, off);
+                if constexpr (A_PL) ldA(i, ok ? a_base[i] + (unsigned)(tap * 6) : kOOB);
+                else ldA(i, ok ? 4u * (a_base[i] + (unsigned)tap) : kOOB);
             }
             if (HAS_MASK && use_scale)
                 rscale = cc < p.Kc ? *reinterpret_cast<const float4 *>(p.in_scale + cc)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
             if (FWDLIKE) {
                 const unsigned wofs = (unsigned)(rs * p.Kc + c0);
+                if constexpr (B_PL) {
 #pragma unroll
-                for (int i = 0; i < BV; ++i)
-                    rb[i] = bload4(rB, cc < p.Kc ? 4u * (b_base[i] + wofs) : kOOB);
+                    for (int i = 0; i < NPB; ++i) ldB(i, b_base[i] + wofs * 6u);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < BV; ++i) ldB(i, cc < p.Kc ? 4u * (b_base[i] + wofs) : kOOB);
+                }
             } else {
                 const unsigned wofs = (unsigned)(c0 * p.ldb + rs * p.cin);
 #pragma unroll
@@ -756,12 +884,22 @@ conv_gemm_kernel(const GemmParams p)
                 put_t(pb, PLB, wb_c4 * 4, wb_k, eb);
                 return;
             }
+            if constexpr (A_PL) {
 #pragma unroll
-            for (int i = 0; i < AV; ++i) {
-                float4 v = ra[i];
-                if (HAS_MASK && use_mask) v = relu_mask(v, rm[i]);
-                if (HAS_MASK && use_scale) v = mul4(v, rscale);
-                put(pa, PLA, kc_row + KC_RPP * i, v);
+                for (int i = 0; i < NPA; ++i) *reinterpret_cast<u32x4 *>(pa + pl_lds(i, PLA)) = pa_[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < AV; ++i) {
+                    float4 v = ra[i];
+                    if (HAS_MASK && use_mask) v = relu_mask(v, rm[i]);
+                    if (HAS_MASK && use_scale) v = mul4(v, rscale);
+                    put(pa, PLA, kc_row + KC_RPP * i, v);
+                }
+            }
+            if constexpr (B_PL) {
+#pragma unroll
+                for (int i = 0; i < NPB; ++i) *reinterpret_cast<u32x4 *>(pb + pl_lds(i, PLB)) = pb_[i];
+                return;
             }
 #pragma unroll
             for (int i = 0; i < BV; ++i) {
@@ -863,6 +1001,9 @@ conv_gemm_kernel(const GemmParams p)
                             (((ks * 4 + lk * 2) ^ swz(wn * (32 * TN) + j * 32 + li)) << 2));
             };
             frag(0, fa[0], fb[0]);
+#ifndef MRCNN_DBG_NOGLOBAL
+            issue_loads();
+#endif
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 if (ks + 1 < BK / 16) frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
@@ -876,6 +1017,14 @@ conv_gemm_kernel(const GemmParams p)
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 fa[ks & 1][i][QA[c]], fb[ks & 1][j][QB[c]], acc[i][j], 0, 0, 0);
+            }
+            if constexpr (ILV) {
+                // issue order: first fragments, then the first K step's MFMAs with one global load
+                // and the second K step's fragment reads dealt out between them, then the rest
+                constexpr int NFR = 3 * (TM + TN), NMH = 6 * TM * TN;
+                __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
+                sgb_interleave<NA + NB, NMH, NFR>();
+                __builtin_amdgcn_sched_group_barrier(0x008, NMH * (BK / 16 - 1), 0);
             }
             return;
         }
@@ -925,6 +1074,7 @@ conv_gemm_kernel(const GemmParams p)
     if (MRCNN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(2);
     if (nslices > 0) {
         load_slice(0);
+        issue_loads();
         store_slice(0);
     }
     if (SINGLEBUF) {
@@ -959,7 +1109,14 @@ conv_gemm_kernel(const GemmParams p)
 #endif
             TRACE1(2)
 #ifndef MRCNN_DBG_NOGLOBAL    // ablation: no global loads in the loop (results are garbage)
-            if (kt + 1 < nslices) load_slice(kt + 1);
+            if (kt + 1 < nslices) {
+                load_slice(kt + 1);
+            } else if constexpr (ILV) {      // (compute() issues the loads: none left)
+#pragma unroll
+                for (int i = 0; i < NA; ++i) oa[i] = kOOB;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) ob[i] = kOOB;
+            }
 #endif
             TRACE1(3)
             compute(0);
@@ -1050,6 +1207,10 @@ conv_gemm_kernel(const GemmParams p)
         const int c4 = lane % F4, r_in = lane / F4;
         const int col = n0 + wn * CW + c4 * 4;
         const bool col_ok = col < p.N;
+        // planes of the output, written beside it (whole-tile launches only: K-split pieces hold
+        // partial sums, their rows get their planes from splitk_epilogue_kernel)
+        const bool emit_pl = SPLIT && !tail && !slab_rows && p.C_pl != nullptr;     // uniform
+        const __amdgpu_buffer_rsrc_t rCpl = make_rsrc(emit_pl ? p.C_pl + zb * p.batch_c * 3 : nullptr, p.cpl_bytes);
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scale4 = make_float4(1.f, 1.f, 1.f, 1.f);
         float4 shift4 = bias4;
         if (col_ok) {
@@ -1090,21 +1251,23 @@ conv_gemm_kernel(const GemmParams p)
                 if (i == 0) { PROBE2(3) } else { PROBE2(5) }
 #pragma unroll
                 for (int kg = 0; kg < NK; kg += QG) {
-                    unsigned off[QG];
+                    unsigned off[QG], poff[QG];
                     float4 v[QG], a0[QG], a1[QG], a2[QG], a3[QG];
 #pragma unroll
                     for (int q = 0; q < QG; ++q) {
                         const int r = (kg + q) * RPI + r_in;
                         v[q] = *reinterpret_cast<const float4 *>(ep + r * LDW + c4 * 4);
                         const int row = m0 + wm * (32 * TM) + i * 32 + r;
-                        int o;
+                        int orow;
                         if (!natural) {
                             const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
-                            o = pr.n < p.perm_n ? (pr.n * (p.gp * p.gq) + pr.pos) * p.ldc + col : -1;
+                            orow = pr.n < p.perm_n ? pr.n * (p.gp * p.gq) + pr.pos : -1;
                         } else {
-                            o = (row - e_row0) * e_ldc + col;
+                            orow = row - e_row0;
                         }
-                        off[q] = (col_ok && row < p.M && o >= 0) ? 4u * (unsigned)o : kOOB;
+                        const bool ok = col_ok && row < p.M && orow >= 0;
+                        off[q] = ok ? 4u * (unsigned)(orow * e_ldc + col) : kOOB;
+                        if (SPLIT) poff[q] = ok ? plane_off((unsigned)(e_ldc * 6), (unsigned)orow, (unsigned)col, 0) : kOOB;
                     }
                     if (c_res) {
 #pragma unroll
@@ -1150,6 +1313,16 @@ conv_gemm_kernel(const GemmParams p)
                             x[t] = y;
                         }
                         bstore4(rC, off[q], make_float4(x[0], x[1], x[2], x[3]));
+                        if constexpr (SPLIT) {
+                            if (emit_pl) {
+                                unsigned h0, m0_, l0, h1, m1, l1;
+                                split3(x[0], x[1], h0, m0_, l0);
+                                split3(x[2], x[3], h1, m1, l1);
+                                bstore8(rCpl, poff[q], h0, h1);
+                                bstore8(rCpl, poff[q] + 64u, m0_, m1);
+                                bstore8(rCpl, poff[q] + 128u, l0, l1);
+                            }
+                        }
                     }
                 }
                 if (i == 0) { PROBE2(4) } else { PROBE2(6) }
@@ -1334,6 +1507,46 @@ conv_gemm_kernel(const GemmParams p)
 #endif
 }
 
+// fp32 [rows][L] (L % 32 == 0) -> plane image (see "operand planes"): 8 elements per thread
+__global__ void __launch_bounds__(256) split_planes_kernel(const float *__restrict__ x,
+                                                           unsigned short *__restrict__ pl, int64_t n8,
+                                                           int L)
+{
+    const int l8 = L >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / l8;
+        const int col = (int)(i - row * l8) << 3;
+        const float4 a = reinterpret_cast<const float4 *>(x)[2 * i];
+        const float4 b = reinterpret_cast<const float4 *>(x)[2 * i + 1];
+        unsigned h[4], m[4], l[4];
+        split3(a.x, a.y, h[0], m[0], l[0]);
+        split3(a.z, a.w, h[1], m[1], l[1]);
+        split3(b.x, b.y, h[2], m[2], l[2]);
+        split3(b.z, b.w, h[3], m[3], l[3]);
+        char *q = reinterpret_cast<char *>(pl) + row * ((int64_t)L * 6) + (col >> 5) * kPlaneChunkBytes +
+                  (col & 31) * 2;
+        *reinterpret_cast<uint4 *>(q) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4 *>(q + 64) = make_uint4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<uint4 *>(q + 128) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
+int launch_split_planes(const float *x, void *planes, int64_t rows, int L, hipStream_t s)
+{
+    MRCNN_REQUIRE(x && planes && rows >= 0 && L > 0 && L % 32 == 0,
+                  "split_planes: null pointer or row length %d not a multiple of 32", L);
+    MRCNN_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)planes % 16) == 0,
+                  "split_planes: pointers must be 16-byte aligned");
+    const int64_t n8 = rows * (L / 8);
+    if (n8 == 0) return 0;
+    const int64_t blocks = std::min<int64_t>(mrcnn::ceil_div(n8, 256), 256 * 32);
+    mrcnn::ProfScope prof(mrcnn::PROF_ELEMENTWISE, 0., 10.0 * (double)rows * L, s);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x,
+                       (unsigned short *)planes, n8, L);
+    return mrcnn::check_launch("split_planes");
+}
+
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, int64_t n,
                                      int64_t stride, float *__restrict__ out)
 {
@@ -1367,7 +1580,8 @@ constexpr int64_t kSlotsBig = 512, kSlotsSmall = 1024;
 int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM launch (lowers
                        // the resident workgroups per CU for co-residency experiments)
 
-int g_split_bf16 = 0;  // mrcnn_set_tuning("split_bf16", 0/1): opt-in split-operand kernel (see SPLIT)
+int g_split_bf16 = 3;  // mrcnn_set_tuning("split_bf16"): bit 0 = 128x128 kernels, bit 1 = 64x64 forward form on the
+                       // split-operand arithmetic (see SPLIT; the default since round 4), 0 = fp32 MFMA everywhere
 int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal start-up stagger; 0 = off)
 int g_stagger_min_rounds = 2;
 
@@ -1416,6 +1630,22 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
     }
     if constexpr (MODE == FWD && TM == TN && (TM == 1 || TM == 2)) {
         if (g_split_bf16 & (TM == 2 ? 1 : 2)) {
+            // operand planes (GemmParams::A_pl / B_pl): filter planes alone, or both operands
+            const bool b_pl = p.B_pl != nullptr, a_pl = b_pl && p.A_pl != nullptr && !MASKED;
+            if constexpr (!MASKED) {
+                if (a_pl) {
+                    hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true, 3>),
+                                       dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0,
+                                          ev1, 0, p);
+                    return;
+                }
+            }
+            if (b_pl) {
+                hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true, 2>),
+                                   dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1,
+                                      0, p);
+                return;
+            }
             hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
                                dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1, 0,
                                   p);
@@ -1450,10 +1680,20 @@ void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
     const double bytes = 4.0 * ((double)rows * p.N + (double)rows * p.Kc + (double)p.N * kdepth);
     // profiler buckets follow the kernel SYMBOL (what rocprofv3 reports): the forward-form
     // instantiation runs forward convolutions and the transposed-filter dgrads alike
-    mrcnn::ProfKernelScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
-                                    (TM >= 2 ? 0 : 1),
-                                flops, bytes);
-    launch_kernel<TM, TN, MODE>(p, blocks, splits, s);
+    {
+        mrcnn::ProfKernelScope prof((MODE == FWD ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_DGRAD_128) +
+                                        (TM >= 2 ? 0 : 1),
+                                    flops, bytes);
+        launch_kernel<TM, TN, MODE>(p, blocks, splits, s);
+    }
+    // output planes: only the wide epilogue of the 128x128 SPLIT forward-form kernel writes them
+    // itself; rows finished by any other whole-tile kernel are split by a pass over those rows
+    // (launch() has made sure the rows are in natural order)
+    const bool inline_planes = MODE == FWD && TM >= 2 && (g_split_bf16 & 1) && MRCNN_GEMM_WIDE_EPILOGUE != 0;
+    if (p.C_pl && p.split_len == 0 && !inline_planes)
+        launch_split_planes(p.C + (int64_t)m_lo * p.ldc,
+                            reinterpret_cast<char *>(p.C_pl) + (int64_t)m_lo * p.ldc * 6, m_hi - m_lo,
+                            p.ldc, s);
 }
 
 // ---- split-K for the leftover rows of a small-M forward / dgrad ----------------------------
@@ -1471,6 +1711,7 @@ struct FixParams {
     int splits, rows, N, row0, ldc, flags;
     int perm_n, pq;      // position-major GEMM rows (see GemmParams::perm_n), positions per image
     int64_t stride;
+    unsigned short *C_pl;   // planes of the output (see GemmParams::C_pl) or NULL
 };
 
 __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const FixParams f)
@@ -1505,6 +1746,16 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const FixParams f)
         v[k] = x;
     }
     *reinterpret_cast<float4 *>(f.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+    if (f.C_pl) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(v[0], v[1], h0, m0, l0);
+        split3(v[2], v[3], h1, m1, l1);
+        char *q = reinterpret_cast<char *>(f.C_pl) + (int64_t)orow * ((int64_t)f.ldc * 6) +
+                  (c >> 5) * kPlaneChunkBytes + (c & 31) * 2;
+        *reinterpret_cast<uint2 *>(q) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(q + 64) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2 *>(q + 128) = make_uint2(l0, l1);
+    }
 }
 
 template <int MODE>
@@ -1523,6 +1774,7 @@ void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_s
     q.C = p.split_ws;
     q.flags = 0;
     q.bias = q.scale = q.shift = q.residual = q.res_g = q.res_y = q.out_mask_y = nullptr;
+    q.C_pl = nullptr;                  // the slabs hold partial sums: planes come from the slab sum
     q.split_len = (int)mrcnn::ceil_div(total_slices, splits);
     splits = (int)mrcnn::ceil_div(total_slices, q.split_len);
     q.split_stride = (int64_t)rows_left * p.N;
@@ -1536,6 +1788,7 @@ void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_s
     f.splits = splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_lo; f.ldc = p.ldc;
     f.flags = p.flags; f.stride = q.split_stride;
     f.perm_n = MODE == FWD ? p.perm_n : 0; f.pq = p.gp * p.gq;
+    f.C_pl = p.C_pl;
     const int64_t n = (int64_t)rows_left * (p.N / 4);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0,
                        s, f);
@@ -1580,6 +1833,8 @@ bool launch_fused_tail(GemmParams p, int rows_main, hipStream_t s)
                                     flops, bytes);
         launch_kernel<TM, TN, MODE>(p, main_tiles + tail_tiles * splits, 1, s);
     }
+    if (p.C_pl && !(MODE == FWD && TM >= 2 && (g_split_bf16 & 1) && MRCNN_GEMM_WIDE_EPILOGUE != 0))
+        launch_split_planes(p.C, p.C_pl, rows_main, p.ldc, s);   // (the tail rows: slab-sum kernel)
     FixParams f = {};
     f.ws = p.split_ws; f.C = p.C;
     f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.residual = p.residual;
@@ -1587,6 +1842,7 @@ bool launch_fused_tail(GemmParams p, int rows_main, hipStream_t s)
     f.splits = (int)splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_main; f.ldc = p.ldc;
     f.flags = p.flags; f.stride = p.tail_stride;
     f.perm_n = MODE == FWD ? p.perm_n : 0; f.pq = p.gp * p.gq;
+    f.C_pl = p.C_pl;
     const int64_t n = (int64_t)rows_left * (p.N / 4);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0,
                        s, f);
@@ -1661,8 +1917,22 @@ void launch_small(const GemmParams &p, hipStream_t s)
 // 1568) the rows of the full rounds run as 128x128 tiles and the leftover rows as a second,
 // short launch of 64x64 tiles, instead of one nearly idle round of big tiles.
 template <int MODE>
-int launch(const GemmParams &p, int splits, hipStream_t s)
+int launch(const GemmParams &p0, int splits, hipStream_t s)
 {
+    GemmParams p = p0;
+    // Operand planes feed the SPLIT forward-form kernels only; output planes are written row by
+    // row next to a plain NHWC output — any other launch gets them from a pass over the finished
+    // output (the caller's contract is: on return the planes it asked for are queued).
+    unsigned short *late_pl = nullptr;
+    if (MODE != FWD || !(g_split_bf16 & 3) || p.Kc % BK != 0 || p.stem) p.A_pl = p.B_pl = nullptr;
+    if (p.C_pl) {
+        MRCNN_REQUIRE(p.out_mode == OUT_PLAIN && p.ldc == p.N && p.N % 32 == 0 && splits == 1,
+                      "conv: output planes need a plain output whose channel count is a multiple of 32 (N=%d)", p.N);
+        if (MODE != FWD || p.perm_n > 0) {
+            late_pl = p.C_pl;
+            p.C_pl = nullptr;
+        }
+    }
     const int64_t tm = mrcnn::ceil_div(p.M, 128), tn = mrcnn::ceil_div(p.N, 128);
     const int64_t T = tm * tn;
     const bool big_ok = p.N > 64 && p.M > 64;
@@ -1688,6 +1958,8 @@ int launch(const GemmParams &p, int splits, hipStream_t s)
             if (rows_main < p.M) launch_remainder<MODE>(p, rows_main, s);
         }
     }
+    if (late_pl)
+        return launch_split_planes(p.C, late_pl, (int64_t)p.c_bytes / 4 / p.ldc, p.ldc, s);
     return mrcnn::check_launch("conv_gemm");
 }
 
@@ -1831,10 +2103,41 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     return 1;
 }
 
+namespace {
+// planes argument of the *_pl entry points -> GemmParams (extents: 6 bytes per element)
+int set_planes(GemmParams &p, const mrcnn_planes *pl, int64_t a_elems, int64_t b_elems, int64_t c_elems)
+{
+    if (!pl) return 0;
+    const int64_t lim = (int64_t)1 << 31;
+    MRCNN_REQUIRE(a_elems * 6 < lim && b_elems * 6 < lim && c_elems * 6 < lim,
+                  "conv: a plane image exceeds 2 GiB; split the batch");
+    MRCNN_REQUIRE(((uintptr_t)pl->a % 16) == 0 && ((uintptr_t)pl->b % 16) == 0 && ((uintptr_t)pl->c % 16) == 0,
+                  "conv: plane images must be 16-byte aligned");
+    p.A_pl = (const unsigned short *)pl->a; p.apl_bytes = (unsigned)(a_elems * 6);
+    p.B_pl = (const unsigned short *)pl->b; p.bpl_bytes = (unsigned)(b_elems * 6);
+    p.C_pl = (unsigned short *)pl->c; p.cpl_bytes = (unsigned)(c_elems * 6);
+    return 0;
+}
+}  // namespace
+
+extern "C" int mrcnn_split_planes(const float *x, void *planes, int64_t rows, int row_len, void *stream)
+{
+    return launch_split_planes(x, planes, rows, row_len, mrcnn::as_stream(stream));
+}
+
 extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                                 const float *bias, const float *scale, const float *shift,
                                 const float *residual, float *y, int epi_flags, void *split_ws,
                                 void *stream)
+{
+    return mrcnn_conv2d_fwd_pl(d, x, w, bias, scale, shift, residual, y, epi_flags, split_ws, nullptr,
+                               stream);
+}
+
+extern "C" int mrcnn_conv2d_fwd_pl(const mrcnn_conv_desc *d, const float *x, const float *w,
+                                   const float *bias, const float *scale, const float *shift,
+                                   const float *residual, float *y, int epi_flags, void *split_ws,
+                                   const mrcnn_planes *planes, void *stream)
 {
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
@@ -1855,6 +2158,9 @@ extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const 
     if (p.perm_n) p.M = (int)(mrcnn::ceil_div(d->N, kPermBlock) * kPermBlock) * d->P * d->Q;
     if (int rc = set_extents(p, (int64_t)d->N * d->H * d->W * d->C, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->P * d->Q * d->K))
+        return rc;
+    if (int rc = set_planes(p, planes, (int64_t)d->N * d->H * d->W * d->C,
+                            (int64_t)d->K * d->R * d->S * d->C, (int64_t)d->N * d->P * d->Q * d->K))
         return rc;
     return launch<FWD>(p, 1, mrcnn::as_stream(stream));
 }
@@ -2050,6 +2356,17 @@ extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, 
                                      const float *res_y, const float *out_mask_y,
                                      const float *out_scale, void *split_ws, void *stream)
 {
+    return mrcnn_conv2d_dgrad_wt_pl(d, gy, wT, gx, epi_flags, mask_y, in_scale, res_g, res_y, out_mask_y,
+                                    out_scale, split_ws, nullptr, stream);
+}
+
+extern "C" int mrcnn_conv2d_dgrad_wt_pl(const mrcnn_conv_desc *d, const float *gy, const float *wT,
+                                        float *gx, int epi_flags, const float *mask_y,
+                                        const float *in_scale, const float *res_g,
+                                        const float *res_y, const float *out_mask_y,
+                                        const float *out_scale, void *split_ws,
+                                        const mrcnn_planes *planes, void *stream)
+{
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(d->stride == 1, "conv2d_dgrad_wt: stride must be 1");
     MRCNN_REQUIRE(gy && wT && gx, "conv2d_dgrad_wt: null pointer");
@@ -2073,6 +2390,10 @@ extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, 
     if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->H * d->W * d->C))
         return rc;
+    if (int rc = set_planes(p, planes, (int64_t)d->N * d->P * d->Q * d->K,
+                            (int64_t)d->K * d->R * d->S * d->C, (int64_t)d->N * d->H * d->W * d->C))
+        return rc;
+    if (mask_y || in_scale) p.A_pl = nullptr;     // a masked gy is split while it is staged
     return launch<FWD>(p, 1, mrcnn::as_stream(stream));
 }
 

@@ -538,19 +538,23 @@ _wino_u_cache = {}
 
 
 # ---- arithmetic of the convolution GEMMs ----------------------------------------------------
-# 'fp32' (default): exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  'split_bf16x3' (opt-in): every
-# operand element is split EXACTLY into three bf16 values (8 + 8 + 8 significand bits) while it is
-# staged, and a K step runs six bf16 MFMAs (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) with fp32
-# accumulation; the dropped cross terms are <= 2^-24 of a product each, so the result carries the
-# error of an fp32 GEMM (tests/test_gpu_split_bf16.py: measured against float64 next to the fp32
-# kernel) at 2.7x the matrix-pipe rate.  Covers the forward-form kernels (forward, stride-1 data
-# gradient, the Winograd per-frequency GEMMs) and the 128x128 weight gradient; everything else
-# (strided data gradient, position-major weight gradient, 64x64 weight gradient) stays on fp32 MFMA.
-GEMM_ARITHMETIC = 'fp32'
+# 'split_bf16x3' (default since round 4): every fp32 operand element is split EXACTLY into three
+# bf16 values (8 + 8 + 8 significand bits) while it is staged, and a K step runs six bf16 MFMAs
+# (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) with fp32 accumulation; the dropped cross terms are
+# <= 2^-24 of a product each — the size of ONE fp32 rounding — so the result carries the error of an
+# fp32 GEMM (tests/test_gpu_split_bf16.py measures it against float64 next to the fp32-MFMA
+# kernels': smaller on every case) at 2.7x the matrix-pipe rate (gfx950 has no TF32 / xf32 and its
+# fp32 MFMA runs at 1/16 of the bf16 rate).  Covers the forward-form kernels (forward, stride-1 data
+# gradient, the Winograd per-frequency GEMMs) and the 128x128 weight gradient; the strided data
+# gradient, the position-major and the 64x64 weight gradient stay on fp32 MFMA.
+# 'fp32': v_mfma_f32_32x32x2_f32 everywhere (the default up to round 3; bench.py reports it as
+# `fp32_mfma`).
+DEFAULT_GEMM_ARITHMETIC = 'split_bf16x3'
+GEMM_ARITHMETIC = DEFAULT_GEMM_ARITHMETIC
 
 
 def set_gemm_arithmetic(kind):
-    """Select 'fp32' or 'split_bf16x3' for the convolution GEMM kernels (process-wide)."""
+    """Select 'split_bf16x3' (default) or 'fp32' for the convolution GEMM kernels (process-wide)."""
     global GEMM_ARITHMETIC
     if kind not in ('fp32', 'split_bf16x3'):
         raise ValueError("gemm arithmetic must be 'fp32' or 'split_bf16x3', got %r" % (kind,))

@@ -14,6 +14,8 @@ from ._layout import nhwc, empty_nhwc
 
 # Pixel-owner backward (no atomics, fixed summation order); False = atomic gather form.
 DETERMINISTIC_BACKWARD = True
+# debug / test switch: check that ``order`` is a permutation of 0..R-1 (one device sort + a read-back)
+VALIDATE_ORDER = False
 
 
 class _ROIAlign2DFn(torch.autograd.Function):

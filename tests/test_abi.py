@@ -113,16 +113,18 @@ def test_kernel_selection_switches_without_device(lib):
     from chainer_mask_rcnn_amd import _lib
     from chainer_mask_rcnn_amd.functions import conv
     assert lib.mrcnn_set_tuning(b'split_bf16', 0) == 0
+    assert lib.mrcnn_set_tuning(b'split_bf16', 3) == 0
     rc = lib.mrcnn_set_tuning(b'no_such_switch', 1)
     assert rc != 0 and b'unknown option' in lib.mrcnn_last_error()
     with pytest.raises(_lib.MrcnnHipError):
         _lib.set_tuning('no_such_switch', 1)
     with pytest.raises(ValueError):
         conv.set_gemm_arithmetic('bf16')
-    conv.set_gemm_arithmetic('split_bf16x3')
-    assert conv.GEMM_ARITHMETIC == 'split_bf16x3'
+    assert conv.DEFAULT_GEMM_ARITHMETIC == 'split_bf16x3'
     conv.set_gemm_arithmetic('fp32')
     assert conv.GEMM_ARITHMETIC == 'fp32'
+    conv.set_gemm_arithmetic('split_bf16x3')
+    assert conv.GEMM_ARITHMETIC == 'split_bf16x3'
 
 
 def test_roi_spatial_order_is_a_permutation_grouped_by_image_and_band():

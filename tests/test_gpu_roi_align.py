@@ -117,6 +117,32 @@ def test_processing_order_does_not_change_the_result(dev):
     with pytest.raises(TypeError):
         F.roi_align_2d(torch.tensor(x, device=dev), torch.tensor(rois, device=dev), 14, 14, 1 / 16.,
                        axes='yx', order=torch.zeros(R, dtype=torch.int64, device=dev))
+    # debug switch: a non-permutation (duplicate / out-of-range entries) is rejected, and the
+    # backward entry point refuses a workspace smaller than its own size query
+    import importlib
+    ra_mod = importlib.import_module('chainer_mask_rcnn_amd.functions.roi_align_2d')
+    from chainer_mask_rcnn_amd import _lib
+    ra_mod.VALIDATE_ORDER = True
+    try:
+        bad = torch.tensor(orders[1], device=dev).clone()
+        bad[3] = bad[4]
+        with pytest.raises(ValueError):
+            F.roi_align_2d(torch.tensor(x, device=dev), torch.tensor(rois, device=dev), 14, 14, 1 / 16.,
+                           axes='yx', order=bad)
+        F.roi_align_2d(torch.tensor(x, device=dev), torch.tensor(rois, device=dev), 14, 14, 1 / 16.,
+                       axes='yx', order=torch.tensor(orders[1], device=dev))
+    finally:
+        ra_mod.VALIDATE_ORDER = False
+    need = _lib.load().mrcnn_roi_align_bwd_workspace_bytes(N, H, W, R, 14, 14, 2)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    gyc = gy.contiguous(memory_format=torch.channels_last)
+    gx = torch.empty((N, H, W, C), device=dev)
+    args = (_lib.ptr(gyc), _lib.ptr(torch.tensor(rois[:, [0, 2, 1, 4, 3]].copy(), device=dev)), _lib.ptr(gx),
+            N, H, W, C, R, 14, 14, 2, 1 / 16., 0, _lib.ptr(ws))
+    with pytest.raises(_lib.MrcnnHipError):
+        _lib.call('mrcnn_roi_align_bwd_ws', *args, need // 2, _lib.stream_ptr())
+    _lib.call('mrcnn_roi_align_bwd_ws', *args, need, _lib.stream_ptr())
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize('sr', [0, 1, 2])

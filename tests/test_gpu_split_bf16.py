@@ -1,16 +1,18 @@
-"""The opt-in split-operand GEMM kernels (functions.conv.set_gemm_arithmetic('split_bf16x3'),
-csrc/conv_gemm.hip SPLIT): every fp32 operand element is staged as three bf16 values whose sum is
-the element exactly, six bf16 MFMAs per K step, fp32 accumulation.  Three statements:
+"""The two arithmetics of the convolution GEMMs (functions.conv.set_gemm_arithmetic,
+csrc/conv_gemm.hip SPLIT).  'split_bf16x3' — the default since round 4 — stages every fp32 operand
+element as three bf16 values whose sum is the element exactly and runs six bf16 MFMAs per K step
+with fp32 accumulation; 'fp32' is fp32 MFMA everywhere.  Three statements:
 
 (1) ACCURACY.  Against float64 on the same fp32 inputs the split kernels' error is at the fp32 MFMA
     kernel's level (rms within 1.5x, max below 1e-5 of the tensor scale) for the forward form, the
     data gradient and the weight gradient — i.e. this is fp32 arithmetic, not a reduced precision.
-(2) PARITY.  The parity tests of the fp32 kernels (tests/test_gpu_conv.py, test_gpu_winograd.py:
-    NumPy oracle, north star's 1e-4 per element) pass unchanged with the split kernels selected,
-    on the tile shapes the full-size step uses (128x128 forced by the `big_min_tiles` knob, since the
-    test problems are small) and on the 64x64 ones.
+(2) PARITY.  The parity tests of the convolution family (tests/test_gpu_conv.py,
+    test_gpu_winograd.py: NumPy oracle, north star's 1e-4 per element — they run on the default
+    arithmetic in their own files) pass on BOTH arithmetics, on the tile shapes the full-size step
+    uses (128x128 forced by the `big_min_tiles` knob, since the test problems are small) and on
+    the 64x64 ones.
 (3) WHOLE GRAPH.  The well-posed train-step criterion of tests/test_gpu_model.py (ReLU decisions
-    against float64 + every gradient entry given the decisions, 1e-4) holds in split mode."""
+    against float64 + every gradient entry given the decisions, 1e-4) holds on both."""
 import numpy as np
 import pytest
 import torch
@@ -24,20 +26,21 @@ import test_gpu_model as TM
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['full-size tile policy', '128x128 tiles forced'])
+@pytest.fixture(params=['fp32 MFMA, full-size tile policy', 'fp32 MFMA, 128x128 tiles forced',
+                        'split operands, 128x128 tiles forced'])
 def split(dev, request):
-    C.set_gemm_arithmetic('split_bf16x3')
-    if request.param.startswith('128'):
+    C.set_gemm_arithmetic('fp32' if request.param.startswith('fp32') else 'split_bf16x3')
+    if '128x128' in request.param:
         _lib.set_tuning('big_min_tiles', 1)
     yield request.param
     _lib.set_tuning('big_min_tiles', 384)
-    C.set_gemm_arithmetic('fp32')
+    C.set_gemm_arithmetic(C.DEFAULT_GEMM_ARITHMETIC)
 
 
 def test_switch_rejects_unknown_arithmetic(dev):
     with pytest.raises(ValueError):
         C.set_gemm_arithmetic('bf16')
-    assert C.GEMM_ARITHMETIC == 'fp32'
+    assert C.GEMM_ARITHMETIC == C.DEFAULT_GEMM_ARITHMETIC == 'split_bf16x3'
 
 
 def _errors(got, ref):
@@ -76,7 +79,7 @@ def test_error_against_float64_is_at_the_fp32_kernels_level(dev, case):
             torch.cuda.synchronize()
             out[kind] = (y.detach(), xt.grad, wt.grad)
     finally:
-        C.set_gemm_arithmetic('fp32')
+        C.set_gemm_arithmetic(C.DEFAULT_GEMM_ARITHMETIC)
         _lib.set_tuning('big_min_tiles', 384)
     for what, a, b, ref in zip(('forward', 'data gradient', 'weight gradient'), out['fp32'],
                                out['split_bf16x3'], refs):
@@ -119,7 +122,7 @@ def test_winograd_route(dev, split, case):
 
 
 def test_train_step_given_the_relu_decisions(dev, split, monkeypatch):
-    if not split.startswith('128'):
+    if '128x128' not in split:
         pytest.skip('the small test model only reaches the 128x128 kernels when they are forced')
     setup = TM._build(dev, 50)
     TM.test_train_step_gradients_given_the_relu_decisions(dev, setup, monkeypatch, True)

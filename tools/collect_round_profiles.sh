@@ -3,7 +3,7 @@
 # command and separate FETCH_SIZE / WRITE_SIZE PMC passes (resident-batch segment only).
 TAG=$1
 R=$GRAFT_REPO_ROOT
-ONLY="--rotate-batches 0 --no-fg-capped --no-device-targets --no-direct-head-forward --no-split-bf16 --pipeline-examples 0"
+ONLY="--rotate-batches 0 --no-fg-capped --no-device-targets --no-direct-head-forward --no-fp32-mfma --pipeline-examples 0"
 python $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
 python $R/bench.py --profile-all --no-cpu-baseline $ONLY > $R/gpurun_out/${TAG}_bench_allkinds.json 2>> $R/gpurun_out/${TAG}_bench.err
 python $R/bench.py --workload infer --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_bench_infer.json 2>> $R/gpurun_out/${TAG}_bench.err
@@ -14,8 +14,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/$
 ls $R/gpurun_out | grep ${TAG}
 python $R/bench.py --force-dp --no-cpu-baseline $ONLY > $R/gpurun_out/${TAG}_bench_dp1.json 2>> $R/gpurun_out/${TAG}_bench.err
 python $R/bench.py --layers 101 --no-cpu-baseline $ONLY > $R/gpurun_out/${TAG}_bench_r101.json 2>> $R/gpurun_out/${TAG}_bench.err
-# the opt-in split-operand kernels: bench line with every GEMM kind timed + kernel stats of the same command
-python $R/bench.py --profile-all --no-cpu-baseline $ONLY --tune split_bf16=3 > $R/gpurun_out/${TAG}_bench_split_allkinds.json 2>> $R/gpurun_out/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_split_stats -o ${TAG}_split -- python $R/bench.py --no-cpu-baseline $ONLY --tune split_bf16=3 > $R/gpurun_out/${TAG}_split_stats.log 2>&1
-python $R/bench.py --layers 101 --no-cpu-baseline $ONLY --tune split_bf16=3 > $R/gpurun_out/${TAG}_bench_split_r101.json 2>> $R/gpurun_out/${TAG}_bench.err
-python $R/bench.py --force-dp --no-cpu-baseline $ONLY --tune split_bf16=3 > $R/gpurun_out/${TAG}_bench_split_dp1.json 2>> $R/gpurun_out/${TAG}_bench.err
+# the fp32-MFMA kernels (the default arithmetic up to round 3): bench line with every GEMM kind timed + kernel stats
+python $R/bench.py --profile-all --no-cpu-baseline $ONLY --tune split_bf16=0 > $R/gpurun_out/${TAG}_bench_fp32_allkinds.json 2>> $R/gpurun_out/${TAG}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_fp32_stats -o ${TAG}_fp32 -- python $R/bench.py --no-cpu-baseline $ONLY --tune split_bf16=0 > $R/gpurun_out/${TAG}_fp32_stats.log 2>&1
+python $R/bench.py --layers 101 --no-cpu-baseline $ONLY --tune split_bf16=0 > $R/gpurun_out/${TAG}_bench_fp32_r101.json 2>> $R/gpurun_out/${TAG}_bench.err

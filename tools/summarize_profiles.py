@@ -6,7 +6,8 @@ g, p = os.path.join(root, 'gpurun_out'), os.path.join(root, 'profiles')
 os.makedirs(p, exist_ok=True)
 shutil.copy(os.path.join(g, '%s_stats' % tag, '%s_kernel_stats.csv' % tag),
             os.path.join(p, '%s_kernel_stats.csv' % tag))
-for name in ('bench', 'bench_allkinds', 'bench_infer', 'bench_dp1', 'bench_r101'):
+for name in ('bench', 'bench_allkinds', 'bench_infer', 'bench_dp1', 'bench_r101', 'bench_fp32_allkinds',
+             'bench_fp32_r101'):
     src = os.path.join(g, '%s_%s.json' % (tag, name))
     if os.path.exists(src):
         lines = [l for l in open(src).read().splitlines() if l.startswith('{')]
@@ -22,6 +23,9 @@ def agg(path, cname):
     return acc
 
 
+src = os.path.join(g, '%s_fp32_stats' % tag, '%s_fp32_kernel_stats.csv' % tag)
+if os.path.exists(src):
+    shutil.copy(src, os.path.join(p, '%s_fp32_kernel_stats.csv' % tag))
 f = agg(os.path.join(g, '%s_fetch' % tag, '%s_counter_collection.csv' % tag), 'FETCH_SIZE')
 w = agg(os.path.join(g, '%s_write' % tag, '%s_counter_collection.csv' % tag), 'WRITE_SIZE')
 out = {k: {'launches': f[k][0], 'FETCH_SIZE_KB_per_launch': f[k][1] / f[k][0],
