@@ -37,6 +37,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MRCNN_GEMM_BK 32
 #endif
 constexpr int BK = MRCNN_GEMM_BK;
+#ifndef MRCNN_GEMM_LOAD_AUX       // cache policy bits of the staged operand loads (experiment)
+#define MRCNN_GEMM_LOAD_AUX 0
+#endif
 #ifndef MRCNN_GEMM_SETPRIO
 #define MRCNN_GEMM_SETPRIO 0
 #endif
@@ -245,7 +248,7 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
 #ifdef MRCNN_DBG_NOLOAD   // experiment: every staged load hits the out-of-range path
     off = kOOB;
 #endif
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, MRCNN_GEMM_LOAD_AUX);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
                        __uint_as_float(v.w));
 }
@@ -350,16 +353,19 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &
 // error of one fp32 multiply-add, so results stay fp32-accurate (tests/test_gpu_split_bf16.py
 // measures the error against float64 next to the fp32 MFMA kernel's), while the matrix pipe
 // does 6 x 32 instead of 8 x 64 cycles per 32x32x16 block.
-// G groups of (MFMAs, one global load, LDS reads) covering NM MFMAs and ND LDS reads in total
-template <int G, int NM, int ND, int I = 0>
+// G groups of (MFMAs, one global load, LDS reads): the loads are dealt out evenly over ALL NM MFMAs
+// of the K slice, the ND LDS reads (next K step's fragments) over the first NMD of them.
+template <int G, int NM, int NMD, int ND, int I = 0>
 __device__ __forceinline__ void sgb_interleave()
 {
     if constexpr (I < G) {
-        constexpr int m = NM * (I + 1) / G - NM * I / G, d = ND * (I + 1) / G - ND * I / G;
-        if constexpr (m > 0) __builtin_amdgcn_sched_group_barrier(0x008, m, 0);
+        constexpr int m0 = NM * I / G, m1 = NM * (I + 1) / G;
+        // LDS reads that belong in front of MFMA m1 (all of them once m1 >= NMD)
+        constexpr int d0 = m0 >= NMD ? ND : ND * m0 / NMD, d1 = m1 >= NMD ? ND : ND * m1 / NMD;
+        if constexpr (m1 > m0) __builtin_amdgcn_sched_group_barrier(0x008, m1 - m0, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        if constexpr (d > 0) __builtin_amdgcn_sched_group_barrier(0x100, d, 0);
-        sgb_interleave<G, NM, ND, I + 1>();
+        if constexpr (d1 > d0) __builtin_amdgcn_sched_group_barrier(0x100, d1 - d0, 0);
+        sgb_interleave<G, NM, NMD, ND, I + 1>();
     }
 }
 
@@ -669,6 +675,9 @@ conv_gemm_kernel(const GemmParams p)
     // (s_memtime stamps) before its first MFMA.
     unsigned oa[ILV ? NA : 1], ob[ILV ? NB : 1];
     auto ldA = [&](int i, unsigned off) {
+#ifdef MRCNN_DBG_NOLOAD_A     // ablation: the A operand's loads take the out-of-range path
+        off = kOOB;
+#endif
         if constexpr (ILV) {
             oa[i] = off;
         } else if constexpr (A_PL) {
@@ -679,6 +688,9 @@ conv_gemm_kernel(const GemmParams p)
         }
     };
     auto ldB = [&](int i, unsigned off) {
+#ifdef MRCNN_DBG_NOLOAD_B
+        off = kOOB;
+#endif
         if constexpr (ILV) ob[i] = off;
         else if constexpr (B_PL) pb_[i] = bload16(rBpl, off);
         else rb[i] = bload4(rB, off);
@@ -1023,8 +1035,16 @@ conv_gemm_kernel(const GemmParams p)
                 // and the second K step's fragment reads dealt out between them, then the rest
                 constexpr int NFR = 3 * (TM + TN), NMH = 6 * TM * TN;
                 __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
-                sgb_interleave<NA + NB, NMH, NFR>();
+#if MRCNN_SPLIT_ILV == 2      // (A/B: loads bunched into the first K step's MFMAs)
+                sgb_interleave<NA + NB, NMH, NMH, NFR>();
                 __builtin_amdgcn_sched_group_barrier(0x008, NMH * (BK / 16 - 1), 0);
+#else
+                // the CU's texture path takes ~64 cycles per 16-byte-per-lane wave load whoever
+                // issues it (tools/exp/planes_probe.py ablations: kernel time = compute + 64 cycles
+                // x loads): a wave whose load waits for its slot issues no MFMA either, so the
+                // loads sit as far apart as the slice allows — one per NM / (NA + NB) MFMAs
+                sgb_interleave<NA + NB, NMH * (BK / 16), NMH * (BK / 16 - 1) - 2 * TM * TN, NFR>();
+#endif
             }
             return;
         }
@@ -2162,6 +2182,14 @@ extern "C" int mrcnn_conv2d_fwd_pl(const mrcnn_conv_desc *d, const float *x, con
     if (int rc = set_planes(p, planes, (int64_t)d->N * d->H * d->W * d->C,
                             (int64_t)d->K * d->R * d->S * d->C, (int64_t)d->N * d->P * d->Q * d->K))
         return rc;
+#ifdef MRCNN_DBG_PITCH      // experiment: rows of x and w MRCNN_DBG_PITCH floats apart (caller over-allocates)
+    if (d->R == 1 && d->stride == 1) {
+        p.lda = d->C + MRCNN_DBG_PITCH; p.ldb = d->C + MRCNN_DBG_PITCH;
+        p.a_bytes = (unsigned)((int64_t)d->N * d->H * d->W * p.lda * 4);
+        p.b_bytes = (unsigned)((int64_t)d->K * p.ldb * 4);
+        p.A_pl = p.B_pl = nullptr;
+    }
+#endif
     return launch<FWD>(p, 1, mrcnn::as_stream(stream));
 }
 

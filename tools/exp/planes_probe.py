@@ -57,8 +57,12 @@ def main():
     for name, N, C, H, W, K, k, s, p in SHAPES:
         if only and only not in name:
             continue
-        x = torch.randn((N, H, W, C), device=dev).permute(0, 3, 1, 2)
-        w = (torch.randn((K, k, k, C), device=dev) * 0.05).permute(0, 3, 1, 2)
+        PAD = int(os.environ.get('PROBE_PITCH', 0))     # variant builds with -DMRCNN_DBG_PITCH read padded rows
+        x = torch.randn((N, H, W, C + PAD), device=dev)[..., :C].permute(0, 3, 1, 2)
+        w = (torch.randn((K, k, k, C + PAD), device=dev) * 0.05)[..., :C].permute(0, 3, 1, 2)
+        if PAD:
+            x = torch.randn((N * H * W * (C + PAD),), device=dev)[:N * H * W * C].view(N, H, W, C).permute(0, 3, 1, 2)
+            w = (torch.randn((K * k * k * (C + PAD),), device=dev) * 0.05)[:K * k * k * C].view(K, k, k, C).permute(0, 3, 1, 2)
         d = make_desc(x.shape, w.shape, s, p)
         esc = torch.rand((K,), device=dev) + 0.5
         esh = torch.randn((K,), device=dev)

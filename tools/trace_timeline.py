@@ -7,11 +7,13 @@ import csv, re, sys
 def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
-    m = re.match(r'conv_gemm_kernel<(\d), (\d), (\d), (\w+), (\w+)>', name)
+    m = re.match(r'conv_gemm_kernel<(\d), (\d), (\d), (\w+), (\w+)(?:, (\w+))?(?:, (\d))?>', name)
     if m:
-        return 'gemm<%s%s,%s%s%s>' % (m.group(1), m.group(2), 'FDW'[int(m.group(3))],
-                                     ',M' if m.group(4) == 'true' else '',
-                                     ',P' if m.group(5) == 'true' else '')
+        return 'gemm<%s%s,%s%s%s%s%s>' % (m.group(1), m.group(2), 'FDW'[int(m.group(3))],
+                                         ',M' if m.group(4) == 'true' else '',
+                                         ',P' if m.group(5) == 'true' else '',
+                                         ',S' if m.group(6) == 'true' else '',
+                                         ',pl%s' % m.group(7) if m.group(7) not in (None, '0') else '')
     name = re.sub(r'at::native::', 'at::', name)
     return name.split('(')[0][:60]
 
