@@ -399,10 +399,17 @@ conv_gemm_kernel(const GemmParams p)
     __shared__ __attribute__((aligned(16))) float smem_all[1][SINGLEBUF ? 1 : 2][STAGE_FLOATS];
 
     float (*smem)[STAGE_FLOATS] = smem_all[0];
-    // SPLIT WGRAD: the 8-byte chunk index inside a plane row is XORed with an EVEN number that
-    // depends on the row's group of 16 (16-byte pairs stay together for the b128 fragment reads);
-    // the transposing writes of one instruction hit rows 4 apart, which would otherwise share banks
-    auto swz = [](int row) { return !SPLIT ? 0 : MODE == WGRAD ? ((row >> 4) & 3) << 1 : ((row >> 2) & 3) << 1; };
+    // SPLIT WGRAD (80-byte rows, no swizzle): plane row 32 c + l holds channel 4 l + c of the tile
+    // (WROWPERM).  The transposing writes of one instruction cover the channels 4 l + c of 32
+    // lanes l: with the channel as the row they would sit 320 bytes apart — two bank positions
+    // for the whole wave — and an XOR of the chunk index that spreads them breaks the b128
+    // fragment reads instead (a read group spans rows r .. r + 27; round-4 PMC: half of the
+    // LDS-active cycles of the former layout were bank conflicts).  With the permuted rows the
+    // lanes of a write hit CONSECUTIVE rows (80 l mod 128: two-way, hidden by the store's own
+    // register transfer) and a fragment read 16 rows with 16 different bank slots; the
+    // permutation is undone where the tile is written (gw row 4 rr + .., column 4 li + ..).
+    constexpr bool WROWPERM = SPLIT && MODE == WGRAD;
+    auto swz = [](int row) { return !SPLIT || MODE == WGRAD ? 0 : ((row >> 2) & 3) << 1; };
     const int tid = threadIdx.x;
 #ifdef MRCNN_GEMM_CLOCKPROBE
     const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime();
@@ -876,7 +883,7 @@ conv_gemm_kernel(const GemmParams p)
                         unsigned h0, m0_, l0, h1, m1, l1;
                         split3(e[0][c], e[1][c], h0, m0_, l0);
                         split3(e[2][c], e[3][c], h1, m1, l1);
-                        const int row = row0 + c;
+                        const int row = 32 * c + (row0 >> 2);      // channel row0 + c (WROWPERM)
                         unsigned short *q = plane0 + row * SROW + ((kchunk ^ swz(row)) << 2);
                         *reinterpret_cast<uint2 *>(q) = make_uint2(h0, h1);
                         *reinterpret_cast<uint2 *>(q + plane_len) = make_uint2(m0_, m1);
@@ -1368,6 +1375,36 @@ conv_gemm_kernel(const GemmParams p)
         default: run(std::integral_constant<int, -1>()); break;
         }
 #undef MRCNN_EPI_CASE
+        return;
+    }
+    if constexpr (WROWPERM) {
+        // tile rows / columns are in plane-row order: fragment row 32 c + l = channel 4 l + c.  A
+        // lane's two column tiles (j = 0, 1) are the ADJACENT columns 4 li + 2 wn + j: one 8-byte
+        // store per accumulator row.
+        static_assert(TM == 2 && TN == 2, "SPLIT WGRAD: 128x128 tiles");
+        const int col = n0 + 4 * li + 2 * wn;
+        const bool col_ok = col < p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int g = 0; g < 16 / EG; ++g) {
+                unsigned off[EG];
+                float row_scale[EG];
+#pragma unroll
+                for (int q = 0; q < EG; ++q) {
+                    const int e = g * EG + q;
+                    const int row = m0 + 4 * ((e & 3) + 8 * (e >> 2) + 4 * lk) + 2 * wm + i;
+                    off[q] = (col_ok && row < p.M) ? 4u * (unsigned)(row * e_ldc + col) : kOOB;
+                    row_scale[q] = (p.scale && row < p.M) ? p.scale[row] : 1.f;
+                }
+#pragma unroll
+                for (int q = 0; q < EG; ++q) {
+                    const float v0 = acc[i][0][g * EG + q] * row_scale[q];
+                    const float v1 = acc[i][1][g * EG + q] * row_scale[q];
+                    bstore8(rC, off[q], __float_as_uint(v0), __float_as_uint(v1));
+                }
+            }
+        }
         return;
     }
 #pragma unroll

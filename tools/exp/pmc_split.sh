@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/exp/pmc_split.sh "<bench_conv filter>"  -> PMC passes of the split-operand kernels
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT
-export BENCH_TUNE=${BENCH_TUNE:-split_bf16=1}
+export BENCH_TUNE=${BENCH_TUNE:-split_bf16=3}
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU" \
