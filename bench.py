@@ -316,21 +316,29 @@ def bench_infer(args, device, rank):
         conv = {k: v for k, v in prof.items() if k.startswith('conv_gemm')}
         gflop = sum(v['flops'] for v in conv.values()) / 1e9
         ms = sum(v['total_ms'] for v in conv.values())
+        from chainer_mask_rcnn_amd.functions import conv as conv_mod
+        split = conv_mod.GEMM_ARITHMETIC == 'split_bf16x3' and 'split_bf16=0' not in args.tune
+        infer_peak = SPLIT_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        infer_note = ('split-operand arithmetic: dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32 '
+                      'multiply-add; achieved = nominal fp32 flops / kernel time') if split else \
+            'fp32 MFMA (v_mfma_f32_32x32x2_f32)'
         emit_json(dict(
             metric='images/sec inference, ResNet%d-C4 Mask R-CNN, 8x1024x1024' % args.layers,
             value=round(args.steps * batch / elapsed, 3), unit='images/sec', n_gpus=1,
             steps=args.steps, warmup=args.warmup,
             ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
-            scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+            scaling='weak', vs_baseline=None,
+            dtype='f32 (operands split into 3 x bf16, six bf16 MFMAs per K step, f32 accumulate)' if split else 'f32',
+            data='synthetic',
             config=dict(workload='BASELINE configs[4]: ResNet%d-C4 inference, batch %dx%dx%d, '
                         '1000 proposals/img, per-class NMS + mask head' % (args.layers, batch, H, W),
                         detections_per_image=n_det,
                         executed_gemm_gflop_per_image=round(gflop / args.steps / batch, 1),
                         gemm_tflops=round(gflop / ms, 2)),
             roofline=dict(bound='mfma', kernel='conv_gemm_kernel (all instantiations)',
-                          achieved=round(gflop / ms, 2), peak=FP32_MFMA_PEAK_TFLOPS,
-                          unit='TFLOP/s', frac=round(gflop / ms / FP32_MFMA_PEAK_TFLOPS, 4),
-                          traffic=None,
+                          achieved=round(gflop / ms, 2), peak=infer_peak,
+                          unit='TFLOP/s', frac=round(gflop / ms / infer_peak, 4),
+                          peak_note=infer_note, traffic=None,
                           kernels={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
                                            launches_per_step=v['launches'] / args.steps)
                                    for k, v in prof.items()})))
