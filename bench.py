@@ -822,7 +822,10 @@ def main():
             roofline['peak_note'] = ('split-operand arithmetic: peak = dense bf16 MFMA 2500 TFLOP/s / 6 '
                                      'products per fp32 multiply-add; achieved = nominal fp32 flops / '
                                      'kernel time (the matrix pipe executes 6x as many bf16 flops: '
-                                     '%.0f of 2500 TFLOP/s)' % (6 * ach))
+                                     '%.0f of 2500 TFLOP/s).  Peak at the nominal 2.4 GHz; under these '
+                                     'kernels the shader clock sits at 1.75-1.94 GHz (power envelope, '
+                                     'profiles/r04_clockprobe_split.txt; the fp32-MFMA kernels run at '
+                                     '2.35-2.39 GHz)' % (6 * ach))
         if rotating is not None:
             out['rotating_h2d'] = rotating
         if pipeline is not None:

@@ -1294,7 +1294,7 @@ conv_gemm_kernel(const GemmParams p)
                         }
                         const bool ok = col_ok && row < p.M && orow >= 0;
                         off[q] = ok ? 4u * (unsigned)(orow * e_ldc + col) : kOOB;
-                        if (SPLIT) poff[q] = ok ? plane_off((unsigned)(e_ldc * 6), (unsigned)orow, (unsigned)col, 0) : kOOB;
+                        if (SPLIT && emit_pl) poff[q] = ok ? plane_off((unsigned)(e_ldc * 6), (unsigned)orow, (unsigned)col, 0) : kOOB;
                     }
                     if (c_res) {
 #pragma unroll
