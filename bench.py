@@ -430,6 +430,9 @@ def main():
     ap.add_argument('--no-fp32-mfma', '--no-split-bf16', dest='fp32_mfma', action='store_false',
                     help='skip the extra measurement on the fp32-MFMA GEMM kernels (the default arithmetic '
                          'up to round 3)')
+    ap.add_argument('--arithmetic', choices=['split_bf16x3', 'fp32'], default=None,
+                    help="GEMM arithmetic of the headline measurement (default: the package's default, "
+                         "split_bf16x3; 'fp32' = fp32 MFMA everywhere, the headline of rounds 1-3)")
     ap.add_argument('--tune', default='',
                     help='developer: comma-separated mrcnn_set_tuning knobs, e.g. small_m_split=4')
     ap.add_argument('--bucket-mb', type=float, default=16.0,
@@ -462,6 +465,9 @@ def main():
         if '=' in kv:
             k, v = kv.split('=')
             _lib.check(_lib.load().mrcnn_set_tuning(k.encode(), int(v)), 'set_tuning')
+    if args.arithmetic is not None:
+        from chainer_mask_rcnn_amd.functions import conv as _conv_mod
+        _conv_mod.set_gemm_arithmetic(args.arithmetic)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device; there is no CPU path')
     torch.cuda.set_device(local)
@@ -685,7 +691,7 @@ def main():
             prof_f = {} if args.no_profile else profile_summary()
             lib.mrcnn_profile_enable(0)
         finally:
-            conv_mod.set_gemm_arithmetic(conv_mod.DEFAULT_GEMM_ARITHMETIC)
+            conv_mod.set_gemm_arithmetic(main_arithmetic)
         fp32_run = dict(value=round(args.steps * args.batch * world / el_s, 3), unit='images/sec',
                         ms_per_step=round(el_s / args.steps * 1e3, 3),
                         workload="same step, functions.conv.set_gemm_arithmetic('fp32'): every GEMM on "
