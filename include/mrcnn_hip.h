@@ -209,10 +209,11 @@ int64_t mrcnn_conv2d_split_workspace_bytes(void);
  *   they fill the CUs while the final round drains) instead of a separate remainder launch;
  *   summation order of those rows differs between the two settings (both deterministic).
  * Arithmetic selection (NOT results-identical: same accuracy class, different rounding):
- *   "split_bf16" (default 0 = exact fp32 MFMA; bit 0: the 128x128 forward-form and weight-gradient
- *   kernels, bit 1: the 64x64 forward-form kernel): operands are staged as three bf16 planes whose
- *   sum is the fp32 element exactly, six bf16 MFMAs per K step, fp32 accumulation.  Error against
- *   float64 is at the fp32 kernels' level (tests/test_gpu_split_bf16.py).
+ *   "split_bf16" (default 3 since round 4; 0 = fp32 MFMA everywhere; bit 0: the 128x128
+ *   forward-form and weight-gradient kernels, bit 1: the 64x64 forward-form kernel): operands are
+ *   staged as three bf16 planes whose sum is the fp32 element exactly, six bf16 MFMAs per K step,
+ *   fp32 accumulation.  Error against float64 is at (measured: below) the fp32-MFMA kernels' level
+ *   (tests/test_gpu_split_bf16.py, tests/test_split_arithmetic_cpu.py).
  *   "big_min_tiles" (default 384): fewest 128x128 tiles for which the 128x128 kernels are used
  *   (1 forces them; lets small test problems exercise the kernels of the full-size step). */
 int mrcnn_set_tuning(const char *name, int value);
