@@ -831,7 +831,9 @@ def main():
                                      '%.0f of 2500 TFLOP/s).  Peak at the nominal 2.4 GHz; under these '
                                      'kernels the shader clock sits at 1.75-1.94 GHz (power envelope, '
                                      'profiles/r04_clockprobe_split.txt; the fp32-MFMA kernels run at '
-                                     '2.35-2.39 GHz)' % (6 * ach))
+                                     '2.35-2.39 GHz); the matrix pipe alone sustains 270 TFLOP/s of this '
+                                     'arithmetic on random operands (profiles/r04_mfma_energy_probe.txt)'
+                                     % (6 * ach))
         if rotating is not None:
             out['rotating_h2d'] = rotating
         if pipeline is not None:
