@@ -16,7 +16,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // per iteration: every wave owns 2x2 accumulator tiles and walks a 32-deep K slice
-template <int KIND>
+// STAGE bits (bf16x3 only): 1 = 8 global loads per slice (L2-resident), 2 = split3 + 24 plane writes,
+// 4 = the kernel's two workgroup barriers per slice
+template <int KIND, int STAGE = 0>
 __global__ void __launch_bounds__(256, 2) probe(const unsigned *rnd, float *out, int iters)
 {
     __shared__ __attribute__((aligned(16))) unsigned lds[12288];
@@ -29,8 +31,41 @@ __global__ void __launch_bounds__(256, 2) probe(const unsigned *rnd, float *out,
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)
             for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; iacc[i][j][e] = 0; }
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(rnd), 0, 2u << 20, 0x00020000);
+    const unsigned gbase = (blockIdx.x * 4 + wave) * 65536u + (lane >> 3) * 8192u + (lane & 7) * 16u;
+    u32x4 v[8];
+    for (int i = 0; i < 8; ++i) v[i] = (u32x4){lds[lane + i], lds[lane + 64 + i], lds[lane + 128 + i], lds[lane + 192 + i]};
+    unsigned *wr = lds + 8192 + wave * 1024;        // (writes go to a region the fragment reads do not touch)
     for (int it = 0; it < iters; ++it) {
         const unsigned o = (unsigned)(it * 64) & 1023u;
+        if constexpr ((STAGE & 2) != 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float a0 = __uint_as_float(v[i].x), a1 = __uint_as_float(v[i].y), a2 = __uint_as_float(v[i].z), a3 = __uint_as_float(v[i].w);
+                unsigned w[6];
+                {   // split3 of two pairs
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    auto pk = [](float p, float q) { const f32x2 t = {p, q}; return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2)); };
+                    w[0] = pk(a0, a1); a0 -= __uint_as_float(w[0] << 16); a1 -= __uint_as_float(w[0] & 0xffff0000u);
+                    w[1] = pk(a0, a1); a0 -= __uint_as_float(w[1] << 16); a1 -= __uint_as_float(w[1] & 0xffff0000u);
+                    w[2] = pk(a0, a1);
+                    w[3] = pk(a2, a3); a2 -= __uint_as_float(w[3] << 16); a3 -= __uint_as_float(w[3] & 0xffff0000u);
+                    w[4] = pk(a2, a3); a2 -= __uint_as_float(w[4] << 16); a3 -= __uint_as_float(w[4] & 0xffff0000u);
+                    w[5] = pk(a2, a3);
+                }
+                *reinterpret_cast<uint2 *>(&wr[(lane * 2 + i * 128) & 1023]) = make_uint2(w[0], w[3]);
+                *reinterpret_cast<uint2 *>(&wr[(lane * 2 + i * 128 + 256) & 1023]) = make_uint2(w[1], w[4]);
+                *reinterpret_cast<uint2 *>(&wr[(lane * 2 + i * 128 + 512) & 1023]) = make_uint2(w[2], w[5]);
+            }
+        }
+        if constexpr ((STAGE & 4) != 0) __syncthreads();
+        if constexpr ((STAGE & 1) != 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (gbase + (unsigned)(it * 8 + i) * 128u) & ((2u << 20) - 1), 0, 0);
+        }
         if constexpr (KIND == 0) {            // bf16x3: 2 K steps x (2+2) tiles x 3 planes of fragments
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -89,15 +124,17 @@ __global__ void __launch_bounds__(256, 2) probe(const unsigned *rnd, float *out,
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t4], fb[j][t4], acc[i][j], 0, 0, 0);
             }
         }
+        if constexpr ((STAGE & 4) != 0) __syncthreads();
     }
     float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += (float)v[i].x;
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)
             for (int e = 0; e < 16; ++e) s += acc[i][j][e] + (float)iacc[i][j][e];
     if (s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int KIND>
+template <int KIND, int STAGE = 0>
 void run(const unsigned *rnd, float *out, const char *what, int kdepth_per_iter)
 {
     hipEvent_t e0, e1;
@@ -106,7 +143,7 @@ void run(const unsigned *rnd, float *out, const char *what, int kdepth_per_iter)
     int iters = 20000;
     for (int rep = 0; rep < 3; ++rep) {       // the last repetition (~1 s) is the measurement
         hipEventRecord(e0);
-        hipLaunchKernelGGL((probe<KIND>), dim3(blocks), dim3(256), 0, 0, rnd, out, iters);
+        hipLaunchKernelGGL((probe<KIND, STAGE>), dim3(blocks), dim3(256), 0, 0, rnd, out, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -138,6 +175,14 @@ int main(int argc, char **argv)
     hipMalloc(&out, 512 * 256 * 4);
     const char *only = argc > 2 ? argv[2] : "";
     if (!only[0] || only[0] == 'b') run<0>(rnd, out, "bf16x3", 32);
+    if (only[0] == 's') {      // staging components beside the six-product MFMAs
+        run<0, 0>(rnd, out, "mfma", 32);
+        run<0, 1>(rnd, out, "+loads", 32);
+        run<0, 2>(rnd, out, "+split", 32);
+        run<0, 4>(rnd, out, "+barr", 32);
+        run<0, 3>(rnd, out, "+ld+sp", 32);
+        run<0, 7>(rnd, out, "+all", 32);
+    }
     if (!only[0] || only[0] == 'i') run<1>(rnd, out, "i8x4", 32);
     if (!only[0] || only[0] == 'f') run<2>(rnd, out, "f32", 32);
     return 0;
