@@ -37,6 +37,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x3
 # (2500 TFLOP/s) per fp32-equivalent multiply-add
 SPLIT_MFMA_PEAK_TFLOPS = round(2500.0 / 6.0, 1)
 HBM_PEAK_GBS = 8000.0
+ARITHMETIC_NOTE = {
+    'split_bf16x3': 'split_bf16x3: fp32 in / fp32 out / fp32 accumulate; every fp32 operand is staged as three '
+                 'bf16 values whose sum is the operand exactly, six bf16 MFMAs per K step (dropped '
+                 'cross terms <= 2^-23 of a product); error against float64 at or below the fp32-MFMA '
+                 'kernels\' (tests/test_gpu_split_bf16.py, tests/test_split_arithmetic_cpu.py)',
+    'fp32': 'fp32 MFMA (v_mfma_f32_32x32x2_f32) in every GEMM kernel'}
 # Algorithmic work of one train step per image: fwd 1076.6 GFLOP,
 # fwd + dgrad + wgrad for every trainable layer, frozen stem/res2 forward only.
 TRAIN_GFLOP_PER_IMAGE = {50: 3157.0, 101: 3644.0}
@@ -328,10 +334,11 @@ def bench_infer(args, device, rank):
             steps=args.steps, warmup=args.warmup,
             ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
             scaling='weak', vs_baseline=None,
-            dtype='f32 (operands split into 3 x bf16, six bf16 MFMAs per K step, f32 accumulate)' if split else 'f32',
+            dtype='f32',
             data='synthetic',
             config=dict(workload='BASELINE configs[4]: ResNet%d-C4 inference, batch %dx%dx%d, '
                         '1000 proposals/img, per-class NMS + mask head' % (args.layers, batch, H, W),
+                        arithmetic=ARITHMETIC_NOTE['split_bf16x3' if split else 'fp32'],
                         detections_per_image=n_det,
                         executed_gemm_gflop_per_image=round(gflop / args.steps / batch, 1),
                         gemm_tflops=round(gflop / ms, 2)),
@@ -796,6 +803,7 @@ def main():
                         args.layers, '+RCCL all-reduce' if sync is not None else '',
                         args.batch, args.height, args.width, n_rois),
             input='resident', global_batch=global_batch, rois_per_image=n_rois // args.batch,
+            arithmetic=ARITHMETIC_NOTE[main_arithmetic],
             # foreground RoIs per image the sampler found on this synthetic batch (the mask branch
             # and its executed flops scale with it; `fg_capped` below pins it at the reference's cap)
             fg_rois_per_image=(n_fg_default / float(args.batch)) if n_fg_default is not None else None,
@@ -824,7 +832,6 @@ def main():
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
             data='synthetic', config=config, roofline=roofline)
         if roofline is not None and roofline['peak'] != FP32_MFMA_PEAK_TFLOPS:
-            out['dtype'] = 'f32 (operands split into 3 x bf16, six bf16 MFMAs per K step, f32 accumulate)'
             roofline['peak_note'] = ('split-operand arithmetic: peak = dense bf16 MFMA 2500 TFLOP/s / 6 '
                                      'products per fp32 multiply-add; achieved = nominal fp32 flops / '
                                      'kernel time (the matrix pipe executes 6x as many bf16 flops: '
