@@ -334,7 +334,7 @@ def bench_infer(args, device, rank):
             steps=args.steps, warmup=args.warmup,
             ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
             scaling='weak', vs_baseline=None,
-            dtype='f32',
+            dtype='f32 (bf16x3 split operands, f32 accumulate)' if split else 'f32',
             data='synthetic',
             config=dict(workload='BASELINE configs[4]: ResNet%d-C4 inference, batch %dx%dx%d, '
                         '1000 proposals/img, per-class NMS + mask head' % (args.layers, batch, H, W),
@@ -829,7 +829,8 @@ def main():
             if args.layers == 50 else 'images/sec train step, ResNet101-C4 Mask R-CNN, COCO 800x1333',
             value=round(value, 3), unit='images/sec', n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
-            higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+            higher_is_better=True, scaling='weak', vs_baseline=None,
+            dtype='f32' if main_arithmetic == 'fp32' else 'f32 (bf16x3 split operands, f32 accumulate)',
             data='synthetic', config=config, roofline=roofline)
         if roofline is not None and roofline['peak'] != FP32_MFMA_PEAK_TFLOPS:
             roofline['peak_note'] = ('split-operand arithmetic: peak = dense bf16 MFMA 2500 TFLOP/s / 6 '
