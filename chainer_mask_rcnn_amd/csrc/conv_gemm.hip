@@ -1,4 +1,4 @@
-// fp32 implicit-GEMM convolution family on MFMA for gfx950 (NHWC / KRSC).
+// Implicit-GEMM convolution family on MFMA for gfx950 (NHWC / KRSC), fp32 in / out.
 //
 // Replaces every cuDNN call the reference makes through chainer's
 // L.Convolution2D / L.Deconvolution2D / L.Linear and their backward passes
@@ -11,8 +11,15 @@
 //   FWD    y[m, k]   = sum_{r,s,c} x[pix(m,r,s), c] * w[k, r, s, c]
 //   DGRAD  gx[m, c]  = sum_{r,s,k} gy[pix'(m,r,s), k] * w[k, r, s, c]
 //   WGRAD  gw[k, rsc] = sum_m gy[m, k] * x[pix(m,r,s), c]      (split over m)
-// All arithmetic is exact fp32 on v_mfma_f32_32x32x2_f32 (157 TF/s peak; there is
-// no TF32/xf32 on gfx950), so results are fp32-roundoff-close to a CPU fp32 GEMM.
+// Two arithmetics, both fp32 in / fp32 out / fp32 accumulate and fp32-roundoff-close to a CPU
+// fp32 GEMM (there is no TF32 / xf32 on gfx950):
+//   SPLIT (default, "split_bf16" knob): every operand element is staged as three bf16 values
+//     whose sum is the element exactly, six v_mfma_f32_32x32x16_bf16 per 16-deep K step (see
+//     SPLIT below); forward form 128x128 / 64x64 and the 128x128 weight gradient.
+//   fp32 MFMA: v_mfma_f32_32x32x2_f32 (157 TF/s peak) — every other instantiation, and all of
+//     them with split_bf16 = 0.
+// The description below is the fp32-MFMA body; the SPLIT instantiations replace its stage
+// layout and its inner product loop only.
 //
 // Tiling (wave64): 256 threads = 2x2 waves, each wave owns TM x TN MFMA tiles of
 // 32x32 (TM=TN=2 -> 128x128 block tile; TM=TN=1 -> 64x64 for small problems).
