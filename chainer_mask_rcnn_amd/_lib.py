@@ -25,13 +25,6 @@ class ConvDesc(ctypes.Structure):
 _DP = ctypes.POINTER(ConvDesc)
 
 
-class Planes(ctypes.Structure):
-    """mrcnn_planes: plane images of the A operand / the filter operand / the output."""
-    _fields_ = [('a', c_vp), ('b', c_vp), ('c', c_vp)]
-
-
-_PP = ctypes.POINTER(Planes)
-
 # name -> (restype, argtypes); every symbol declared in include/mrcnn_hip.h
 SIGNATURES = {
     'mrcnn_last_error': (ctypes.c_char_p, []),
@@ -70,8 +63,6 @@ SIGNATURES = {
     'mrcnn_conv2d_split_workspace_bytes': (c_i64, []),
     'mrcnn_set_tuning': (c_int, [ctypes.c_char_p, c_int]),
     'mrcnn_conv2d_fwd': (c_int, [_DP] + [c_vp] * 7 + [c_int, c_vp, c_vp]),
-    'mrcnn_conv2d_fwd_pl': (c_int, [_DP] + [c_vp] * 7 + [c_int, c_vp, _PP, c_vp]),
-    'mrcnn_split_planes': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     'mrcnn_conv2d_dgrad': (c_int, [_DP, c_vp, c_vp, c_vp, c_int, c_vp]),
     'mrcnn_conv2d_wgrad_workspace_bytes': (c_i64, [_DP]),
     'mrcnn_conv2d_wgrad': (c_int, [_DP, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -88,7 +79,6 @@ SIGNATURES = {
     'mrcnn_filter_flip_transpose': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     'mrcnn_filter_flip_transpose_batched': (c_int, [c_int] + [c_vp] * 8),
     'mrcnn_conv2d_dgrad_wt': (c_int, [_DP, c_vp, c_vp, c_vp, c_int] + [c_vp] * 8),
-    'mrcnn_conv2d_dgrad_wt_pl': (c_int, [_DP, c_vp, c_vp, c_vp, c_int] + [c_vp] * 7 + [_PP, c_vp]),
     'mrcnn_conv_stem_fwd': (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp]),
     'mrcnn_deconv2x2s2_fwd': (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     'mrcnn_deconv2x2s2_dgrad': (c_int, [c_vp] * 3 + [c_int] * 5 + [c_vp]),

@@ -36,6 +36,19 @@
 
 #include "common.h"
 
+// Ablation / instrumentation switches (MRCNN_DBG_*, MRCNN_GEMM_TRACE, MRCNN_GEMM_CLOCKPROBE: several
+// of them produce garbage results by design) compile only in an experiment build
+// (tools/build_variant.sh passes -DMRCNN_EXPERIMENT_BUILD and writes the library under
+// csrc/variants/): a stray EXTRA= on the product build must not ship a silently wrong library.
+#if !defined(MRCNN_EXPERIMENT_BUILD) &&                                                              \
+    (defined(MRCNN_DBG_NOLOAD) || defined(MRCNN_DBG_NOLOAD_A) || defined(MRCNN_DBG_NOLOAD_B) ||      \
+     defined(MRCNN_DBG_NOSTORE) || defined(MRCNN_DBG_NOSPLITVALU) || defined(MRCNN_DBG_NOSPLIT_B) || \
+     defined(MRCNN_DBG_NOSTAGE) || defined(MRCNN_DBG_NOGLOBAL) || defined(MRCNN_DBG_PLAIN_EPI) ||    \
+     defined(MRCNN_DBG_AMOD) || defined(MRCNN_DBG_PITCH) || defined(MRCNN_GEMM_TRACE) ||             \
+     defined(MRCNN_GEMM_CLOCKPROBE) || defined(MRCNN_GEMM_BIGBLOCKS) || defined(MRCNN_SPLIT_PK_SUB))
+#error "MRCNN_DBG_* / trace / probe switches need -DMRCNN_EXPERIMENT_BUILD (tools/build_variant.sh): such a library must never be the product build"
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -179,28 +192,7 @@ struct GemmParams {
     // (b / 256) x stagger_cycles shader cycles before its first load, so the phases interleave.
     // Placement only decides how well this works, never the result.
     int stagger_slots, stagger_cycles;
-    // Pre-split operands (SPLIT forward-form kernels, see "operand planes" below): the three bf16
-    // planes of A / B as written by their producer, and the planes of the output this launch is
-    // to write beside C (any of them NULL: the fp32 tensor is split while it is staged / nothing
-    // is written).  Extents in bytes (< 2 GiB: kOOB must stay out of range).
-    const unsigned short *A_pl, *B_pl;
-    unsigned short *C_pl;
-    unsigned apl_bytes, bpl_bytes, cpl_bytes;
 };
-
-// ---- operand planes -----------------------------------------------------------------------
-// A [rows][L] fp32 matrix whose row length L is a multiple of 32 has a PLANE image of 6 bytes per
-// element: per row, per 32-element chunk, 3 x 32 bf16 = hi | mid | lo (64 bytes each) with
-// x = hi + mid + lo exactly (split3).  A K slice of a row is one contiguous 192-byte run.  The
-// forward-form SPLIT kernels stage such an operand with plain 16-byte copies — the conversion,
-// which otherwise runs once per output-tile column (A) or row (B) that re-reads the element, is
-// done once, by whoever produced the tensor (GEMM epilogue, Winograd transforms, ROIAlign,
-// mrcnn_split_planes).  Results are bit-identical to the in-kernel split.
-constexpr int kPlaneChunkBytes = 192;
-__host__ __device__ __forceinline__ unsigned plane_off(unsigned row_bytes6, unsigned row, unsigned col, unsigned q)
-{
-    return row * row_bytes6 + (col >> 5) * kPlaneChunkBytes + q * 64u + (col & 31u) * 2u;
-}
 
 #ifdef MRCNN_GEMM_TRACE
 __device__ unsigned long long g_trace[64 * 4 * 64 * 5];
@@ -258,13 +250,6 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, MRCNN_GEMM_LOAD_AUX);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
                        __uint_as_float(v.w));
-}
-__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off)
-{
-#ifdef MRCNN_DBG_NOLOAD
-    off = kOOB;
-#endif
-    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
 }
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned off)
 {
@@ -352,7 +337,8 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &
 // Removed; see the history of this file.)
 // WPERM: WGRAD with position-major pixel order (GemmParams::perm_n) — a separate instantiation
 // because the natural-order kernel sits exactly at its 168-register budget.
-// SPLIT (opt-in, mrcnn_set_tuning("split_bf16", 1); forward-form 128x128 launches only): the
+// SPLIT (the default arithmetic; mrcnn_set_tuning("split_bf16", 0) selects fp32 MFMA everywhere;
+// forward form 128x128 / 64x64 and the 128x128 natural-order weight gradient): the
 // operands are staged as THREE bf16 planes each — a = a_hi + a_mid + a_lo EXACTLY (8 + 8 + 8
 // significand bits) — and a K step runs six v_mfma_f32_32x32x16_bf16 (hi*hi, hi*mid, mid*hi,
 // mid*mid, hi*lo, lo*hi; every product of two bf16 values is exact in fp32, accumulation is fp32).
@@ -376,15 +362,11 @@ __device__ __forceinline__ void sgb_interleave()
     }
 }
 
-// PL (SPLIT forward form only): bit 0 = the A operand, bit 1 = the B operand arrive as planes.
-template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false, int PL = 0>
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false>
 __global__ void __launch_bounds__(256, SPLIT ? (TM == 2 ? 2 : 4) : min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
-    static_assert(PL == 0 || (SPLIT && MODE == FWD && !(MASKED && (PL & 1))),
-                  "operand planes: SPLIT forward form; a masked A operand is split in the kernel");
-    constexpr bool A_PL = (PL & 1) != 0, B_PL = (PL & 2) != 0;
     constexpr bool ILV = MRCNN_SPLIT_ILV != 0 && SPLIT && MODE == FWD && !MASKED;
     static_assert(!SPLIT || (BK == 32 && TM == TN &&
                              ((MODE == FWD && (TM == 1 || TM == 2)) || (MODE == WGRAD && !WPERM && TM == 2))),
@@ -416,6 +398,8 @@ conv_gemm_kernel(const GemmParams p)
     // register transfer) and a fragment read 16 rows with 16 different bank slots; the
     // permutation is undone where the tile is written (gw row 4 rr + .., column 4 li + ..).
     constexpr bool WROWPERM = SPLIT && MODE == WGRAD;
+    static_assert(!(WROWPERM && MRCNN_WGRAD_INKERNEL_REDUCE),
+                  "the WROWPERM epilogue returns before the in-kernel slab reduction: gw would stay unwritten");
     auto swz = [](int row) { return !SPLIT || MODE == WGRAD ? 0 : ((row >> 2) & 3) << 1; };
     const int tid = threadIdx.x;
 #ifdef MRCNN_GEMM_CLOCKPROBE
@@ -445,9 +429,6 @@ conv_gemm_kernel(const GemmParams p)
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A + zb * p.batch_a, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rB = make_rsrc(p.B + zb * p.batch_b, p.b_bytes);
     const __amdgpu_buffer_rsrc_t rMask = make_rsrc(p.mask_y, p.a_bytes);
-    // plane images: 3 ushorts per element, batched problems 3 * batch_x ushorts apart
-    const __amdgpu_buffer_rsrc_t rApl = make_rsrc(A_PL ? p.A_pl + zb * p.batch_a * 3 : nullptr, p.apl_bytes);
-    const __amdgpu_buffer_rsrc_t rBpl = make_rsrc(B_PL ? p.B_pl + zb * p.batch_b * 3 : nullptr, p.bpl_bytes);
     const bool use_mask = HAS_MASK && p.mask_y != nullptr;
 
     // tile -> (m0, n0).  Workgroup b runs on XCD b % 8 (observed dispatch order); remap so
@@ -479,19 +460,8 @@ conv_gemm_kernel(const GemmParams p)
     // ---------------- per-thread gather state -----------------------------------
     constexpr int KC_C4 = BK / 4, KC_RPP = 256 / KC_C4;   // float4 per row, rows per pass
     const int kc_row = tid / KC_C4, kc_c4 = tid % KC_C4;
-    // plane operands: a tile's K slice is BM (BN) runs of 192 bytes = 12 pieces of 16 bytes; piece
-    // (tid + 256 i) of the tile -> row (tid + 256 i) / 12, piece pc of its run (plane pc >> 2,
-    // 16-byte slot pc & 3): consecutive lanes read consecutive pieces
-    constexpr int NPA = A_PL ? BM * 12 / 256 : 1, NPB = B_PL ? BN * 12 / 256 : 1;
-    constexpr int NA = A_PL ? NPA : AV;                 // A rows a thread addresses
-    auto pl_row = [&](int i) { return (tid + 256 * i) / 12; };
-    auto pl_pc = [&](int i) { return (tid + 256 * i) % 12; };
-    auto a_row = [&](int i) { return A_PL ? pl_row(i) : kc_row + KC_RPP * i; };
-    // LDS position (ushort index inside an operand's three planes) of plane piece i
-    auto pl_lds = [&](int i, int plane_len) {
-        const int row = pl_row(i), pc = pl_pc(i);
-        return (pc >> 2) * plane_len + row * SROW + (((pc & 3) ^ ((row >> 2) & 3)) << 3);
-    };
+    constexpr int NA = AV;                              // A rows a thread addresses
+    auto a_row = [&](int i) { return kc_row + KC_RPP * i; };
     int a_n[NA], a_y[NA], a_x[NA];     // FWD/DGRAD: pixel coords of each A row
     // 1x1 / stride 1 / pad 0 forward-form launches (two thirds of the RoI head's GEMMs): GEMM row
     // m IS pixel m of the gathered tensor — no (image, y, x) decomposition, i.e. none of the
@@ -629,8 +599,7 @@ conv_gemm_kernel(const GemmParams p)
         }
     }
 
-    float4 ra[A_PL ? 1 : AV], rb[B_PL ? 1 : BV];
-    u32x4 pa_[NPA], pb_[NPB];                // plane pieces in flight (A_PL / B_PL)
+    float4 ra[AV], rb[BV];
     float4 rm[HAS_MASK ? AV : 1];
     float4 rscale = make_float4(1.f, 1.f, 1.f, 1.f);
     const bool use_scale = HAS_MASK && p.in_scale != nullptr;
@@ -640,23 +609,20 @@ conv_gemm_kernel(const GemmParams p)
     // Loop-invariant parts of every load address (element offsets; an invalid row carries the
     // sentinel 0x20000000 so that 4 * offset lands beyond num_records and reads as zero).
     constexpr unsigned kBad = 0x20000000u;
-    // (plane operands: BYTE offsets of the thread's pieces, 6 bytes per element)
-    constexpr int NB = B_PL ? NPB : BV;
+    constexpr int NB = BV;
     unsigned a_base[NA], b_base[NB];
     if (MODE != WGRAD) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const unsigned pix = pointwise ? (unsigned)a_n[i]
                                            : (unsigned)((a_n[i] * p.sh + a_y[i]) * p.sw + a_x[i]);
-            a_base[i] = A_PL ? pix * (unsigned)(p.lda * 6) + (unsigned)(pl_pc(i) * 16)
-                             : pix * (unsigned)p.lda + (unsigned)(kc_c4 * 4);
+            a_base[i] = pix * (unsigned)p.lda + (unsigned)(kc_c4 * 4);
         }
         if (FWDLIKE) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int n = n0 + (B_PL ? pl_row(i) : kc_row + KC_RPP * i);
-                if (B_PL) b_base[i] = n < p.N ? (unsigned)n * (unsigned)(p.ldb * 6) + (unsigned)(pl_pc(i) * 16) : kOOB;
-                else b_base[i] = n < p.N ? (unsigned)(n * p.ldb + kc_c4 * 4) : kBad;
+                const int n = n0 + kc_row + KC_RPP * i;
+                b_base[i] = n < p.N ? (unsigned)(n * p.ldb + kc_c4 * 4) : kBad;
             }
         } else {
 #pragma unroll
@@ -694,8 +660,6 @@ conv_gemm_kernel(const GemmParams p)
 #endif
         if constexpr (ILV) {
             oa[i] = off;
-        } else if constexpr (A_PL) {
-            pa_[i] = bload16(rApl, off);
         } else {
             ra[i] = bload4(rA, off);
             if (HAS_MASK && use_mask) rm[i] = bload4(rMask, off);
@@ -706,21 +670,14 @@ conv_gemm_kernel(const GemmParams p)
         off = kOOB;
 #endif
         if constexpr (ILV) ob[i] = off;
-        else if constexpr (B_PL) pb_[i] = bload16(rBpl, off);
         else rb[i] = bload4(rB, off);
     };
     auto issue_loads = [&]() {
         if constexpr (ILV) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                if constexpr (A_PL) pa_[i] = bload16(rApl, oa[i]);
-                else ra[i] = bload4(rA, oa[i]);
-            }
+            for (int i = 0; i < NA; ++i) ra[i] = bload4(rA, oa[i]);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                if constexpr (B_PL) pb_[i] = bload16(rBpl, ob[i]);
-                else rb[i] = bload4(rB, ob[i]);
-            }
+            for (int i = 0; i < NB; ++i) rb[i] = bload4(rB, ob[i]);
         }
     };
     // issue the global loads of slice kt (nothing here consumes a loaded value).
@@ -735,25 +692,14 @@ conv_gemm_kernel(const GemmParams p)
             const int c0 = (kt + kt0) * BK;
             const int cc = c0 + kc_c4 * 4;
             const bool c_ok = cc < p.Kc;
-            if constexpr (A_PL) {       // (planes: Kc is a multiple of BK, every slice is whole)
 #pragma unroll
-                for (int i = 0; i < NPA; ++i)
-                    ldA(i, a_y[i] == 0 ? a_base[i] + (unsigned)(c0 * 6) : kOOB);
-            } else {
-#pragma unroll
-                for (int i = 0; i < AV; ++i)
-                    ldA(i, (c_ok && a_y[i] == 0) ? 4u * (a_base[i] + (unsigned)c0) : kOOB);
-            }
+            for (int i = 0; i < AV; ++i)
+                ldA(i, (c_ok && a_y[i] == 0) ? 4u * (a_base[i] + (unsigned)c0) : kOOB);
             if (HAS_MASK && use_scale)
                 rscale = c_ok ? *reinterpret_cast<const float4 *>(p.in_scale + cc)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (B_PL) {
 #pragma unroll
-                for (int i = 0; i < NPB; ++i) ldB(i, b_base[i] + (unsigned)(c0 * 6));
-            } else {
-#pragma unroll
-                for (int i = 0; i < BV; ++i) ldB(i, c_ok ? 4u * (b_base[i] + (unsigned)c0) : kOOB);
-            }
+            for (int i = 0; i < BV; ++i) ldB(i, c_ok ? 4u * (b_base[i] + (unsigned)c0) : kOOB);
             return;
         }
         if (FWDLIKE || MODE == DGRAD) {
@@ -778,21 +724,15 @@ conv_gemm_kernel(const GemmParams p)
                 if (FWDLIKE) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? (cc >> 2) : 0); }
                 else { iy = a_y[i] - r; ix = a_x[i] - s; }
                 const bool ok = c_ok && (unsigned)iy < (unsigned)p.sh && (unsigned)ix < (unsigned)p.sw;
-                if constexpr (A_PL) ldA(i, ok ? a_base[i] + (unsigned)(tap * 6) : kOOB);
-                else ldA(i, ok ? 4u * (a_base[i] + (unsigned)tap) : kOOB);
+                ldA(i, ok ? 4u * (a_base[i] + (unsigned)tap) : kOOB);
             }
             if (HAS_MASK && use_scale)
                 rscale = cc < p.Kc ? *reinterpret_cast<const float4 *>(p.in_scale + cc)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
             if (FWDLIKE) {
                 const unsigned wofs = (unsigned)(rs * p.Kc + c0);
-                if constexpr (B_PL) {
 #pragma unroll
-                    for (int i = 0; i < NPB; ++i) ldB(i, b_base[i] + wofs * 6u);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < BV; ++i) ldB(i, cc < p.Kc ? 4u * (b_base[i] + wofs) : kOOB);
-                }
+                for (int i = 0; i < BV; ++i) ldB(i, cc < p.Kc ? 4u * (b_base[i] + wofs) : kOOB);
             } else {
                 const unsigned wofs = (unsigned)(c0 * p.ldb + rs * p.cin);
 #pragma unroll
@@ -910,22 +850,12 @@ conv_gemm_kernel(const GemmParams p)
                 put_t(pb, PLB, wb_c4 * 4, wb_k, eb);
                 return;
             }
-            if constexpr (A_PL) {
 #pragma unroll
-                for (int i = 0; i < NPA; ++i) *reinterpret_cast<u32x4 *>(pa + pl_lds(i, PLA)) = pa_[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < AV; ++i) {
-                    float4 v = ra[i];
-                    if (HAS_MASK && use_mask) v = relu_mask(v, rm[i]);
-                    if (HAS_MASK && use_scale) v = mul4(v, rscale);
-                    put(pa, PLA, kc_row + KC_RPP * i, v);
-                }
-            }
-            if constexpr (B_PL) {
-#pragma unroll
-                for (int i = 0; i < NPB; ++i) *reinterpret_cast<u32x4 *>(pb + pl_lds(i, PLB)) = pb_[i];
-                return;
+            for (int i = 0; i < AV; ++i) {
+                float4 v = ra[i];
+                if (HAS_MASK && use_mask) v = relu_mask(v, rm[i]);
+                if (HAS_MASK && use_scale) v = mul4(v, rscale);
+                put(pa, PLA, kc_row + KC_RPP * i, v);
             }
 #pragma unroll
             for (int i = 0; i < BV; ++i) {
@@ -1241,10 +1171,6 @@ conv_gemm_kernel(const GemmParams p)
         const int c4 = lane % F4, r_in = lane / F4;
         const int col = n0 + wn * CW + c4 * 4;
         const bool col_ok = col < p.N;
-        // planes of the output, written beside it (whole-tile launches only: K-split pieces hold
-        // partial sums, their rows get their planes from splitk_epilogue_kernel)
-        const bool emit_pl = SPLIT && !tail && !slab_rows && p.C_pl != nullptr;     // uniform
-        const __amdgpu_buffer_rsrc_t rCpl = make_rsrc(emit_pl ? p.C_pl + zb * p.batch_c * 3 : nullptr, p.cpl_bytes);
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), scale4 = make_float4(1.f, 1.f, 1.f, 1.f);
         float4 shift4 = bias4;
         if (col_ok) {
@@ -1285,7 +1211,7 @@ conv_gemm_kernel(const GemmParams p)
                 if (i == 0) { PROBE2(3) } else { PROBE2(5) }
 #pragma unroll
                 for (int kg = 0; kg < NK; kg += QG) {
-                    unsigned off[QG], poff[QG];
+                    unsigned off[QG];
                     float4 v[QG], a0[QG], a1[QG], a2[QG], a3[QG];
 #pragma unroll
                     for (int q = 0; q < QG; ++q) {
@@ -1301,7 +1227,6 @@ conv_gemm_kernel(const GemmParams p)
                         }
                         const bool ok = col_ok && row < p.M && orow >= 0;
                         off[q] = ok ? 4u * (unsigned)(orow * e_ldc + col) : kOOB;
-                        if (SPLIT && emit_pl) poff[q] = ok ? plane_off((unsigned)(e_ldc * 6), (unsigned)orow, (unsigned)col, 0) : kOOB;
                     }
                     if (c_res) {
 #pragma unroll
@@ -1347,16 +1272,6 @@ conv_gemm_kernel(const GemmParams p)
                             x[t] = y;
                         }
                         bstore4(rC, off[q], make_float4(x[0], x[1], x[2], x[3]));
-                        if constexpr (SPLIT) {
-                            if (emit_pl) {
-                                unsigned h0, m0_, l0, h1, m1, l1;
-                                split3(x[0], x[1], h0, m0_, l0);
-                                split3(x[2], x[3], h1, m1, l1);
-                                bstore8(rCpl, poff[q], h0, h1);
-                                bstore8(rCpl, poff[q] + 64u, m0_, m1);
-                                bstore8(rCpl, poff[q] + 128u, l0, l1);
-                            }
-                        }
                     }
                 }
                 if (i == 0) { PROBE2(4) } else { PROBE2(6) }
@@ -1571,46 +1486,6 @@ conv_gemm_kernel(const GemmParams p)
 #endif
 }
 
-// fp32 [rows][L] (L % 32 == 0) -> plane image (see "operand planes"): 8 elements per thread
-__global__ void __launch_bounds__(256) split_planes_kernel(const float *__restrict__ x,
-                                                           unsigned short *__restrict__ pl, int64_t n8,
-                                                           int L)
-{
-    const int l8 = L >> 3;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / l8;
-        const int col = (int)(i - row * l8) << 3;
-        const float4 a = reinterpret_cast<const float4 *>(x)[2 * i];
-        const float4 b = reinterpret_cast<const float4 *>(x)[2 * i + 1];
-        unsigned h[4], m[4], l[4];
-        split3(a.x, a.y, h[0], m[0], l[0]);
-        split3(a.z, a.w, h[1], m[1], l[1]);
-        split3(b.x, b.y, h[2], m[2], l[2]);
-        split3(b.z, b.w, h[3], m[3], l[3]);
-        char *q = reinterpret_cast<char *>(pl) + row * ((int64_t)L * 6) + (col >> 5) * kPlaneChunkBytes +
-                  (col & 31) * 2;
-        *reinterpret_cast<uint4 *>(q) = make_uint4(h[0], h[1], h[2], h[3]);
-        *reinterpret_cast<uint4 *>(q + 64) = make_uint4(m[0], m[1], m[2], m[3]);
-        *reinterpret_cast<uint4 *>(q + 128) = make_uint4(l[0], l[1], l[2], l[3]);
-    }
-}
-
-int launch_split_planes(const float *x, void *planes, int64_t rows, int L, hipStream_t s)
-{
-    MRCNN_REQUIRE(x && planes && rows >= 0 && L > 0 && L % 32 == 0,
-                  "split_planes: null pointer or row length %d not a multiple of 32", L);
-    MRCNN_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)planes % 16) == 0,
-                  "split_planes: pointers must be 16-byte aligned");
-    const int64_t n8 = rows * (L / 8);
-    if (n8 == 0) return 0;
-    const int64_t blocks = std::min<int64_t>(mrcnn::ceil_div(n8, 256), 256 * 32);
-    mrcnn::ProfScope prof(mrcnn::PROF_ELEMENTWISE, 0., 10.0 * (double)rows * L, s);
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x,
-                       (unsigned short *)planes, n8, L);
-    return mrcnn::check_launch("split_planes");
-}
-
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, int64_t n,
                                      int64_t stride, float *__restrict__ out)
 {
@@ -1694,22 +1569,6 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
     }
     if constexpr (MODE == FWD && TM == TN && (TM == 1 || TM == 2)) {
         if (g_split_bf16 & (TM == 2 ? 1 : 2)) {
-            // operand planes (GemmParams::A_pl / B_pl): filter planes alone, or both operands
-            const bool b_pl = p.B_pl != nullptr, a_pl = b_pl && p.A_pl != nullptr && !MASKED;
-            if constexpr (!MASKED) {
-                if (a_pl) {
-                    hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true, 3>),
-                                       dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0,
-                                          ev1, 0, p);
-                    return;
-                }
-            }
-            if (b_pl) {
-                hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true, 2>),
-                                   dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1,
-                                      0, p);
-                return;
-            }
             hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
                                dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1, 0,
                                   p);
@@ -1750,14 +1609,6 @@ void launch_tiles(GemmParams p, int m_lo, int m_hi, int splits, hipStream_t s)
                                     flops, bytes);
         launch_kernel<TM, TN, MODE>(p, blocks, splits, s);
     }
-    // output planes: only the wide epilogue of the 128x128 SPLIT forward-form kernel writes them
-    // itself; rows finished by any other whole-tile kernel are split by a pass over those rows
-    // (launch() has made sure the rows are in natural order)
-    const bool inline_planes = MODE == FWD && TM >= 2 && (g_split_bf16 & 1) && MRCNN_GEMM_WIDE_EPILOGUE != 0;
-    if (p.C_pl && p.split_len == 0 && !inline_planes)
-        launch_split_planes(p.C + (int64_t)m_lo * p.ldc,
-                            reinterpret_cast<char *>(p.C_pl) + (int64_t)m_lo * p.ldc * 6, m_hi - m_lo,
-                            p.ldc, s);
 }
 
 // ---- split-K for the leftover rows of a small-M forward / dgrad ----------------------------
@@ -1775,7 +1626,6 @@ struct FixParams {
     int splits, rows, N, row0, ldc, flags;
     int perm_n, pq;      // position-major GEMM rows (see GemmParams::perm_n), positions per image
     int64_t stride;
-    unsigned short *C_pl;   // planes of the output (see GemmParams::C_pl) or NULL
 };
 
 __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const FixParams f)
@@ -1810,16 +1660,6 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const FixParams f)
         v[k] = x;
     }
     *reinterpret_cast<float4 *>(f.C + off) = make_float4(v[0], v[1], v[2], v[3]);
-    if (f.C_pl) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3(v[0], v[1], h0, m0, l0);
-        split3(v[2], v[3], h1, m1, l1);
-        char *q = reinterpret_cast<char *>(f.C_pl) + (int64_t)orow * ((int64_t)f.ldc * 6) +
-                  (c >> 5) * kPlaneChunkBytes + (c & 31) * 2;
-        *reinterpret_cast<uint2 *>(q) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2 *>(q + 64) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2 *>(q + 128) = make_uint2(l0, l1);
-    }
 }
 
 template <int MODE>
@@ -1838,7 +1678,6 @@ void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_s
     q.C = p.split_ws;
     q.flags = 0;
     q.bias = q.scale = q.shift = q.residual = q.res_g = q.res_y = q.out_mask_y = nullptr;
-    q.C_pl = nullptr;                  // the slabs hold partial sums: planes come from the slab sum
     q.split_len = (int)mrcnn::ceil_div(total_slices, splits);
     splits = (int)mrcnn::ceil_div(total_slices, q.split_len);
     q.split_stride = (int64_t)rows_left * p.N;
@@ -1852,7 +1691,6 @@ void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_s
     f.splits = splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_lo; f.ldc = p.ldc;
     f.flags = p.flags; f.stride = q.split_stride;
     f.perm_n = MODE == FWD ? p.perm_n : 0; f.pq = p.gp * p.gq;
-    f.C_pl = p.C_pl;
     const int64_t n = (int64_t)rows_left * (p.N / 4);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0,
                        s, f);
@@ -1897,8 +1735,6 @@ bool launch_fused_tail(GemmParams p, int rows_main, hipStream_t s)
                                     flops, bytes);
         launch_kernel<TM, TN, MODE>(p, main_tiles + tail_tiles * splits, 1, s);
     }
-    if (p.C_pl && !(MODE == FWD && TM >= 2 && (g_split_bf16 & 1) && MRCNN_GEMM_WIDE_EPILOGUE != 0))
-        launch_split_planes(p.C, p.C_pl, rows_main, p.ldc, s);   // (the tail rows: slab-sum kernel)
     FixParams f = {};
     f.ws = p.split_ws; f.C = p.C;
     f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.residual = p.residual;
@@ -1906,7 +1742,6 @@ bool launch_fused_tail(GemmParams p, int rows_main, hipStream_t s)
     f.splits = (int)splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_main; f.ldc = p.ldc;
     f.flags = p.flags; f.stride = p.tail_stride;
     f.perm_n = MODE == FWD ? p.perm_n : 0; f.pq = p.gp * p.gq;
-    f.C_pl = p.C_pl;
     const int64_t n = (int64_t)rows_left * (p.N / 4);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0,
                        s, f);
@@ -1984,19 +1819,6 @@ template <int MODE>
 int launch(const GemmParams &p0, int splits, hipStream_t s)
 {
     GemmParams p = p0;
-    // Operand planes feed the SPLIT forward-form kernels only; output planes are written row by
-    // row next to a plain NHWC output — any other launch gets them from a pass over the finished
-    // output (the caller's contract is: on return the planes it asked for are queued).
-    unsigned short *late_pl = nullptr;
-    if (MODE != FWD || !(g_split_bf16 & 3) || p.Kc % BK != 0 || p.stem) p.A_pl = p.B_pl = nullptr;
-    if (p.C_pl) {
-        MRCNN_REQUIRE(p.out_mode == OUT_PLAIN && p.ldc == p.N && p.N % 32 == 0 && splits == 1,
-                      "conv: output planes need a plain output whose channel count is a multiple of 32 (N=%d)", p.N);
-        if (MODE != FWD || p.perm_n > 0) {
-            late_pl = p.C_pl;
-            p.C_pl = nullptr;
-        }
-    }
     const int64_t tm = mrcnn::ceil_div(p.M, 128), tn = mrcnn::ceil_div(p.N, 128);
     const int64_t T = tm * tn;
     const bool big_ok = p.N > 64 && p.M > 64;
@@ -2022,8 +1844,6 @@ int launch(const GemmParams &p0, int splits, hipStream_t s)
             if (rows_main < p.M) launch_remainder<MODE>(p, rows_main, s);
         }
     }
-    if (late_pl)
-        return launch_split_planes(p.C, late_pl, (int64_t)p.c_bytes / 4 / p.ldc, p.ldc, s);
     return mrcnn::check_launch("conv_gemm");
 }
 
@@ -2167,41 +1987,10 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     return 1;
 }
 
-namespace {
-// planes argument of the *_pl entry points -> GemmParams (extents: 6 bytes per element)
-int set_planes(GemmParams &p, const mrcnn_planes *pl, int64_t a_elems, int64_t b_elems, int64_t c_elems)
-{
-    if (!pl) return 0;
-    const int64_t lim = (int64_t)1 << 31;
-    MRCNN_REQUIRE(a_elems * 6 < lim && b_elems * 6 < lim && c_elems * 6 < lim,
-                  "conv: a plane image exceeds 2 GiB; split the batch");
-    MRCNN_REQUIRE(((uintptr_t)pl->a % 16) == 0 && ((uintptr_t)pl->b % 16) == 0 && ((uintptr_t)pl->c % 16) == 0,
-                  "conv: plane images must be 16-byte aligned");
-    p.A_pl = (const unsigned short *)pl->a; p.apl_bytes = (unsigned)(a_elems * 6);
-    p.B_pl = (const unsigned short *)pl->b; p.bpl_bytes = (unsigned)(b_elems * 6);
-    p.C_pl = (unsigned short *)pl->c; p.cpl_bytes = (unsigned)(c_elems * 6);
-    return 0;
-}
-}  // namespace
-
-extern "C" int mrcnn_split_planes(const float *x, void *planes, int64_t rows, int row_len, void *stream)
-{
-    return launch_split_planes(x, planes, rows, row_len, mrcnn::as_stream(stream));
-}
-
 extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                                 const float *bias, const float *scale, const float *shift,
                                 const float *residual, float *y, int epi_flags, void *split_ws,
                                 void *stream)
-{
-    return mrcnn_conv2d_fwd_pl(d, x, w, bias, scale, shift, residual, y, epi_flags, split_ws, nullptr,
-                               stream);
-}
-
-extern "C" int mrcnn_conv2d_fwd_pl(const mrcnn_conv_desc *d, const float *x, const float *w,
-                                   const float *bias, const float *scale, const float *shift,
-                                   const float *residual, float *y, int epi_flags, void *split_ws,
-                                   const mrcnn_planes *planes, void *stream)
 {
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
@@ -2223,15 +2012,11 @@ extern "C" int mrcnn_conv2d_fwd_pl(const mrcnn_conv_desc *d, const float *x, con
     if (int rc = set_extents(p, (int64_t)d->N * d->H * d->W * d->C, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->P * d->Q * d->K))
         return rc;
-    if (int rc = set_planes(p, planes, (int64_t)d->N * d->H * d->W * d->C,
-                            (int64_t)d->K * d->R * d->S * d->C, (int64_t)d->N * d->P * d->Q * d->K))
-        return rc;
 #ifdef MRCNN_DBG_PITCH      // experiment: rows of x and w MRCNN_DBG_PITCH floats apart (caller over-allocates)
     if (d->R == 1 && d->stride == 1) {
         p.lda = d->C + MRCNN_DBG_PITCH; p.ldb = d->C + MRCNN_DBG_PITCH;
         p.a_bytes = (unsigned)((int64_t)d->N * d->H * d->W * p.lda * 4);
         p.b_bytes = (unsigned)((int64_t)d->K * p.ldb * 4);
-        p.A_pl = p.B_pl = nullptr;
     }
 #endif
     return launch<FWD>(p, 1, mrcnn::as_stream(stream));
@@ -2428,17 +2213,6 @@ extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, 
                                      const float *res_y, const float *out_mask_y,
                                      const float *out_scale, void *split_ws, void *stream)
 {
-    return mrcnn_conv2d_dgrad_wt_pl(d, gy, wT, gx, epi_flags, mask_y, in_scale, res_g, res_y, out_mask_y,
-                                    out_scale, split_ws, nullptr, stream);
-}
-
-extern "C" int mrcnn_conv2d_dgrad_wt_pl(const mrcnn_conv_desc *d, const float *gy, const float *wT,
-                                        float *gx, int epi_flags, const float *mask_y,
-                                        const float *in_scale, const float *res_g,
-                                        const float *res_y, const float *out_mask_y,
-                                        const float *out_scale, void *split_ws,
-                                        const mrcnn_planes *planes, void *stream)
-{
     if (int rc = check_desc(d)) return rc;
     MRCNN_REQUIRE(d->stride == 1, "conv2d_dgrad_wt: stride must be 1");
     MRCNN_REQUIRE(gy && wT && gx, "conv2d_dgrad_wt: null pointer");
@@ -2462,10 +2236,6 @@ extern "C" int mrcnn_conv2d_dgrad_wt_pl(const mrcnn_conv_desc *d, const float *g
     if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->R * d->S * d->C,
                              (int64_t)d->N * d->H * d->W * d->C))
         return rc;
-    if (int rc = set_planes(p, planes, (int64_t)d->N * d->P * d->Q * d->K,
-                            (int64_t)d->K * d->R * d->S * d->C, (int64_t)d->N * d->H * d->W * d->C))
-        return rc;
-    if (mask_y || in_scale) p.A_pl = nullptr;     // a masked gy is split while it is staged
     return launch<FWD>(p, 1, mrcnn::as_stream(stream));
 }
 

@@ -39,17 +39,31 @@ class _PinnedRing(object):
     has completed (its event), so the host never waits for a copy and never for the copy stream's
     other work (the input pipeline's next-batch upload shares that stream)."""
 
+    MAX_BYTES = 256 << 20        # pinned bytes the ring may hold (buffers in flight included)
+
     def __init__(self):
         import threading
         self.lock = threading.Lock()
-        self.free = []           # [(buffer, event of its last copy or None)]
+        self.free = []           # [(buffer, event of its last copy or None)], oldest first
+        self.total = 0           # bytes of every live buffer: the free list + those handed out
 
     def take(self, nbytes):
         with self.lock:
             for i, (buf, ev) in enumerate(self.free):
                 if buf.numel() >= nbytes and (ev is None or ev.query()):
                     return self.free.pop(i)[0]
-        return torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8).pin_memory()
+            size = max(int(nbytes), 1 << 16)
+            # at the cap: wait for the OLDEST copy and recycle / release its buffer instead of
+            # growing (the copy stream is backed up; pinned memory must stay bounded)
+            while self.free and self.total + size > self.MAX_BYTES:
+                buf, ev = self.free.pop(0)
+                if ev is not None:
+                    ev.synchronize()
+                if buf.numel() >= nbytes:
+                    return buf
+                self.total -= buf.numel()
+            self.total += size
+        return torch.empty(size, dtype=torch.uint8).pin_memory()
 
     def give(self, buf, ev):
         with self.lock:
@@ -57,7 +71,7 @@ class _PinnedRing(object):
             if len(self.free) > 16:      # drop the smallest finished one
                 done = [i for i, (b, e) in enumerate(self.free) if e is None or e.query()]
                 if done:
-                    self.free.pop(min(done, key=lambda i: self.free[i][0].numel()))
+                    self.total -= self.free.pop(min(done, key=lambda i: self.free[i][0].numel()))[0].numel()
 
 
 _PINNED = _PinnedRing()
@@ -68,9 +82,9 @@ def _upload(array, dtype, dev):
     stream; the compute stream is ordered after an EVENT recorded right behind this copy — not
     after the whole copy stream, which also carries the input pipeline's next-batch upload and
     its prepare kernels (tools/train_loop.py) — and the host does not wait at all."""
-    if dev.type != 'cuda':
-        return torch.tensor(array, dtype=dtype, device=dev)
-    a = np.ascontiguousarray(array, dtype=_NP_OF[dtype])
+    if dev.type != 'cuda' or dtype not in _NP_OF:
+        return torch.tensor(array, dtype=dtype, device=dev)     # (bool, float64, int16, ...: plain path)
+    a = np.require(np.asarray(array, dtype=_NP_OF[dtype]), requirements='C')    # keeps a 0-d shape
     side = copy_stream(dev)
     main = torch.cuda.current_stream(dev)
     n = a.nbytes

@@ -217,30 +217,6 @@ int64_t mrcnn_conv2d_split_workspace_bytes(void);
  *   "big_min_tiles" (default 384): fewest 128x128 tiles for which the 128x128 kernels are used
  *   (1 forces them; lets small test problems exercise the kernels of the full-size step). */
 int mrcnn_set_tuning(const char *name, int value);
-/* ---- operand planes (split-operand arithmetic, "split_bf16") ---------------------------------
- * A [rows][L] fp32 matrix with L % 32 == 0 has a PLANE image of 6 bytes per element: per row, per
- * 32-element chunk, 3 x 32 bf16 = hi | mid | lo (64 bytes each), x = hi + mid + lo exactly.  The
- * split-operand kernels otherwise derive the three values every time an element is staged — once
- * per output-tile column (activations) or row (filters) that reads it; given the image they stage
- * it with plain copies.  Results are bit-identical either way.  NHWC activations are [pixels][C],
- * KRSC filters [K][R*S*C], the transposed filter of mrcnn_conv2d_dgrad_wt [C][R*S*K].
- *   a: image of the activation / gradient operand (x, gy) or NULL
- *   b: image of the filter operand or NULL
- *   c: where the image of the OUTPUT is to be written (on return it is queued behind the output,
- *      by the GEMM's own epilogue where that is possible, else by a pass over the output) or NULL
- * The images are advisory for a and b: a launch that cannot use one (fp32-MFMA arithmetic, channel
- * counts that are not multiples of 32, masked operands) reads the fp32 tensor. */
-typedef struct mrcnn_planes {
-    const void *a;
-    const void *b;
-    void *c;
-} mrcnn_planes;
-/* x [rows][row_len] -> its plane image (6 * rows * row_len bytes); row_len % 32 == 0. */
-int mrcnn_split_planes(const float *x, void *planes, int64_t rows, int row_len, void *stream);
-int mrcnn_conv2d_fwd_pl(const mrcnn_conv_desc *d, const float *x, const float *w,
-                        const float *bias, const float *scale, const float *shift,
-                        const float *residual, float *y, int epi_flags, void *split_ws,
-                        const mrcnn_planes *planes, void *stream);
 int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                      const float *bias, const float *scale, const float *shift,
                      const float *residual, float *y, int epi_flags, void *split_ws,
@@ -337,12 +313,6 @@ int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, const float
                           const float *in_scale, const float *res_g, const float *res_y,
                           const float *out_mask_y, const float *out_scale, void *split_ws,
                           void *stream);
-/* The same with operand planes (a: gy unless it is masked / scaled while staged, b: wT, c: gx). */
-int mrcnn_conv2d_dgrad_wt_pl(const mrcnn_conv_desc *d, const float *gy, const float *wT,
-                             float *gx, int epi_flags, const float *mask_y,
-                             const float *in_scale, const float *res_g, const float *res_y,
-                             const float *out_mask_y, const float *out_scale, void *split_ws,
-                             const mrcnn_planes *planes, void *stream);
 /* Stem: conv1 7x7/2 pad 3 with bias of chainer ResNet50Layers (SURVEY.md A.1;
  * models/resnet_extractor.py:65-67) fused with bn1-as-affine and ReLU.  x4 is
  * the image padded to 4 channels (N,H,W,4); w784 is the filter laid out

@@ -57,12 +57,7 @@ def test_argument_validation_without_device(lib):
     rc = lib.mrcnn_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None, 0, None,
                               None)
     assert rc != 0 and b'multiples of 4' in lib.mrcnn_last_error()
-    # operand planes: row lengths that are not multiples of 32 have no plane image; misaligned images
     buf = ctypes.create_string_buffer(64)
-    rc = lib.mrcnn_split_planes(ctypes.cast(buf, ctypes.c_void_p), ctypes.cast(buf, ctypes.c_void_p), 1, 48,
-                                None)
-    assert rc != 0 and b'multiple of 32' in lib.mrcnn_last_error()
-    assert lib.mrcnn_split_planes(None, None, 1, 32, None) != 0
     # the ROIAlign backward refuses a workspace smaller than its own size query
     need = lib.mrcnn_roi_align_bwd_workspace_bytes(1, 8, 8, 4, 7, 7, 1)
     assert need > 0

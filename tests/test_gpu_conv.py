@@ -1,5 +1,5 @@
-"""fp32-MFMA implicit-GEMM convolution family vs the NumPy oracle (np_ref) on the
-same seeded inputs.  Tolerance: north_star's 1e-4 relative for fp32 conv, PER ELEMENT:
+"""Implicit-GEMM convolution family (on the default arithmetic: split_bf16x3; tests/test_gpu_split_bf16.py
+re-runs this module on both arithmetics) vs the NumPy oracle (np_ref) on the same seeded inputs.  Tolerance: north_star's 1e-4 relative for fp32 conv, PER ELEMENT:
 |got - ref| <= 1e-4 * |ref| + 1e-5 * max|ref| (the absolute floor covers elements that cancel
 to ~0, where no fp32 summation order has a bounded relative error).  Where it is cheap the
 oracle is evaluated in float64 on the same fp32 inputs, so the bound is on the HIP result's

@@ -126,78 +126,3 @@ def test_train_step_given_the_relu_decisions(dev, split, monkeypatch):
         pytest.skip('the small test model only reaches the 128x128 kernels when they are forced')
     setup = TM._build(dev, 50)
     TM.test_train_step_gradients_given_the_relu_decisions(dev, setup, monkeypatch, True)
-
-
-@pytest.mark.parametrize('case', [
-    # N, C, H, W, K, k, stride, pad: 1x1 pointwise, 3x3 gather, strided 1x1, position-major 3x3
-    # on 7x7 maps (planes of the output written by a pass), a small-M problem (64x64 tiles +
-    # split-K tail) and a K-tile-ragged one
-    (40, 256, 14, 14, 256, 1, 1, 0),
-    (2, 128, 51, 84, 128, 3, 1, 1),
-    (64, 256, 14, 14, 128, 1, 2, 0),
-    (192, 128, 7, 7, 128, 3, 1, 1),
-    (2, 1024, 51, 84, 256, 1, 1, 0),
-    (24, 96, 9, 11, 160, 1, 1, 0),
-])
-@pytest.mark.parametrize('tiles', ['full-size tile policy', '128x128 tiles forced'])
-def test_operand_planes_are_bit_identical_to_the_in_kernel_split(dev, case, tiles):
-    """include/mrcnn_hip.h "operand planes": a forward-form launch fed with the plane images of
-    its operands (mrcnn_split_planes) returns the bits of the launch that splits them while
-    staging, on every gather path; the image it writes of its OUTPUT equals mrcnn_split_planes of
-    that output; the stride-1 data gradient through the transposed filter likewise."""
-    import ctypes
-    N, Cc, H, W, K, k, s, p = case
-    g = torch.Generator(device='cpu').manual_seed(sum(case))
-    x = torch.randn((N, H, W, Cc), generator=g).to(dev).permute(0, 3, 1, 2)
-    w = (torch.randn((K, k, k, Cc), generator=g) / (k * Cc ** 0.5)).to(dev).permute(0, 3, 1, 2)
-    sc = (torch.rand((K,), generator=g) + 0.5).to(dev)
-    sh = torch.randn((K,), generator=g).to(dev)
-    d = C.make_desc(x.shape, w.shape, s, p)
-
-    def planes_of(t, rows, row_len):
-        pl = torch.empty((rows * row_len * 6,), dtype=torch.uint8, device=dev)
-        _lib.call('mrcnn_split_planes', _lib.ptr(t), _lib.ptr(pl), rows, row_len, _lib.stream_ptr())
-        return pl
-
-    C.set_gemm_arithmetic('split_bf16x3')
-    if tiles.startswith('128'):
-        _lib.set_tuning('big_min_tiles', 1)
-    try:
-        x_pl, w_pl = planes_of(x, N * H * W, Cc), planes_of(w, K, k * k * Cc)
-        outs = []
-        for a_pl, b_pl in ((None, None), (None, w_pl), (x_pl, w_pl)):
-            y = C.empty_nhwc((d.N, d.K, d.P, d.Q), dev)
-            y_pl = torch.zeros((d.N * d.P * d.Q * K * 6,), dtype=torch.uint8, device=dev)
-            pl = _lib.Planes(_lib.ptr(a_pl), _lib.ptr(b_pl), _lib.ptr(y_pl))
-            _lib.call('mrcnn_conv2d_fwd_pl', C.ctx_desc(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(sc),
-                      _lib.ptr(sh), None, _lib.ptr(y), 2 | 8, _lib.ptr(C.split_ws(dev)),
-                      ctypes.byref(pl), _lib.stream_ptr())
-            assert torch.equal(y_pl, planes_of(y, d.N * d.P * d.Q, K)), 'output image'
-            outs.append(y)
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-        # an image really is hi | mid | lo with hi + mid + lo == x: decode one row chunk on the host
-        img = x_pl.cpu().numpy().view(np.uint16).reshape(N * H * W, Cc // 32, 3, 32)
-        f32 = (img.astype(np.uint32) << 16).view(np.float32)
-        back = (f32[:, :, 0].astype(np.float64) + f32[:, :, 1] + f32[:, :, 2]).reshape(N * H * W, Cc)
-        assert np.array_equal(back.astype(np.float32),
-                              x.permute(0, 2, 3, 1).reshape(N * H * W, Cc).cpu().numpy())
-        if s == 1:
-            gy = torch.randn((d.N, d.P, d.Q, K), generator=g).to(dev).permute(0, 3, 1, 2)
-            wT = torch.empty((Cc * k * k * K,), device=dev)
-            _lib.call('mrcnn_filter_flip_transpose', _lib.ptr(w), _lib.ptr(wT), K, k, k, Cc, None,
-                      _lib.stream_ptr())
-            gy_pl, wT_pl = planes_of(gy, d.N * d.P * d.Q, K), planes_of(wT, Cc, k * k * K)
-            gxs = []
-            for a_pl, b_pl in ((None, None), (gy_pl, wT_pl)):
-                gx = C.empty_nhwc((N, Cc, H, W), dev)
-                gx_pl = torch.zeros((N * H * W * Cc * 6,), dtype=torch.uint8, device=dev)
-                pl = _lib.Planes(_lib.ptr(a_pl), _lib.ptr(b_pl), _lib.ptr(gx_pl))
-                _lib.call('mrcnn_conv2d_dgrad_wt_pl', C.ctx_desc(d), _lib.ptr(gy), _lib.ptr(wT), _lib.ptr(gx),
-                          0, None, None, None, None, None, None, _lib.ptr(C.split_ws(dev)),
-                          ctypes.byref(pl), _lib.stream_ptr())
-                assert torch.equal(gx_pl, planes_of(gx, N * H * W, Cc)), 'gradient image'
-                gxs.append(gx)
-            assert torch.equal(gxs[0], gxs[1])
-    finally:
-        _lib.set_tuning('big_min_tiles', 384)
-        C.set_gemm_arithmetic(C.DEFAULT_GEMM_ARITHMETIC)
