@@ -39,8 +39,8 @@ SPLIT_MFMA_PEAK_TFLOPS = round(2500.0 / 6.0, 1)
 HBM_PEAK_GBS = 8000.0
 ARITHMETIC_NOTE = {
     'split_bf16x3': 'split_bf16x3: fp32 in / fp32 out / fp32 accumulate; every fp32 operand is staged as three '
-                 'bf16 values whose sum is the operand exactly, six bf16 MFMAs per K step (dropped '
-                 'cross terms <= 2^-23 of a product); error against float64 at or below the fp32-MFMA '
+                 'bf16 values whose sum is the operand exactly, six bf16 MFMAs per K step (the three '
+                 'dropped cross terms: <= 2^-24 of a product each, <= 2^-23 in total); error against float64 at or below the fp32-MFMA '
                  'kernels\' (tests/test_gpu_split_bf16.py, tests/test_split_arithmetic_cpu.py)',
     'fp32': 'fp32 MFMA (v_mfma_f32_32x32x2_f32) in every GEMM kernel'}
 # Algorithmic work of one train step per image: fwd 1076.6 GFLOP,
@@ -154,6 +154,78 @@ def fg_saturated_sampler(base):
     obj = FgSaturated.__new__(FgSaturated)
     obj.__dict__.update(base.__dict__)
     return obj
+
+
+class SmiSampler(object):
+    """Package power and shader clock sampled on a host thread while a timed region runs
+    (librocm_smi64 through ctypes: rsmi_dev_power_get / rsmi_dev_gpu_clk_freq_get, one sample every
+    `period` seconds — a `rocm-smi` subprocess takes longer than the 0.5 s region).  The chip clocks
+    to its power budget (MI355X_MICROARCH.md "DVFS give-back"): a throughput number without the clock
+    and power it was measured at cannot be compared across boxes.  Reported only; every failure
+    (library missing, sensor unsupported) yields None fields, never an exception."""
+
+    def __init__(self, index=0, period=0.01):
+        import threading
+        self.index, self.period = index, period
+        self.samples = []            # (seconds, watts or None, MHz or None)
+        self._stop = threading.Event()
+        self._thread = None
+        self.lib = None
+        try:
+            lib = ctypes.CDLL('librocm_smi64.so')
+            if lib.rsmi_init(ctypes.c_uint64(0)) == 0:
+                self.lib = lib
+        except OSError:
+            pass
+
+    class _Freq(ctypes.Structure):
+        _fields_ = [('has_deep_sleep', ctypes.c_bool), ('num_supported', ctypes.c_uint32),
+                    ('current', ctypes.c_uint32), ('frequency', ctypes.c_uint64 * 33)]
+
+    def read(self):
+        watts = mhz = None
+        if self.lib is None:
+            return watts, mhz
+        p, kind = ctypes.c_uint64(0), ctypes.c_int(0)
+        if self.lib.rsmi_dev_power_get(ctypes.c_uint32(self.index), ctypes.byref(p), ctypes.byref(kind)) == 0:
+            watts = p.value / 1e6
+        f = self._Freq()
+        if self.lib.rsmi_dev_gpu_clk_freq_get(ctypes.c_uint32(self.index), ctypes.c_int(0), ctypes.byref(f)) == 0 \
+                and f.current < 33:
+            mhz = f.frequency[f.current] / 1e6
+        return watts, mhz
+
+    def _loop(self):
+        t0 = time.perf_counter()
+        while not self._stop.is_set():
+            w, m = self.read()
+            self.samples.append((time.perf_counter() - t0, w, m))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        import threading
+        self.samples = []
+        self._stop.clear()
+        if self.lib is not None:
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        return False
+
+    def summary(self):
+        w = [x[1] for x in self.samples if x[1] is not None]
+        m = [x[2] for x in self.samples if x[2] is not None]
+        return dict(power_w=round(float(np.median(w)), 1) if w else None,
+                    power_w_max=round(float(max(w)), 1) if w else None,
+                    sclk_mhz=round(float(np.median(m)), 0) if m else None,
+                    sclk_mhz_min=round(float(min(m)), 0) if m else None,
+                    samples=len(self.samples))
 
 
 def profile_summary():
@@ -278,10 +350,12 @@ def cpu_baseline():
                            phases)))
 
 
-def bench_infer(args, device, rank):
+def bench_infer(args, device, rank, steps=None, warmup=None):
     """BASELINE configs[4]: ResNet50-C4 inference, batch 8 x 1024 x 1024, 1000 proposals/img,
     per-class NMS + mask head on the <= 100 detections/img (MaskRCNN.predict minus the host
-    cv2 prepare/paste, models/mask_rcnn.py:311-335)."""
+    cv2 prepare/paste, models/mask_rcnn.py:311-335).  Returns the JSON object (rank 0) or None."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     import chainer_mask_rcnn_amd as cmr
     from chainer_mask_rcnn_amd import _lib
     torch.manual_seed(0)
@@ -305,19 +379,20 @@ def bench_infer(args, device, rank):
     def step():
         return model.predict_prepared(x, scales, sizes)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         out = step()
     torch.cuda.synchronize()
     lib = _lib.load()
     lib.mrcnn_profile_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = profile_summary()
     lib.mrcnn_profile_enable(0)
     n_det = [len(b) for b in out[0]]
+    del model, x
     if rank == 0:
         conv = {k: v for k, v in prof.items() if k.startswith('conv_gemm')}
         gflop = sum(v['flops'] for v in conv.values()) / 1e9
@@ -328,11 +403,11 @@ def bench_infer(args, device, rank):
         infer_note = ('split-operand arithmetic: dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32 '
                       'multiply-add; achieved = nominal fp32 flops / kernel time') if split else \
             'fp32 MFMA (v_mfma_f32_32x32x2_f32)'
-        emit_json(dict(
+        return dict(
             metric='images/sec inference, ResNet%d-C4 Mask R-CNN, 8x1024x1024' % args.layers,
-            value=round(args.steps * batch / elapsed, 3), unit='images/sec', n_gpus=1,
-            steps=args.steps, warmup=args.warmup,
-            ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
+            value=round(steps * batch / elapsed, 3), unit='images/sec', n_gpus=1,
+            steps=steps, warmup=warmup,
+            ms_per_step=round(elapsed / steps * 1e3, 3), higher_is_better=True,
             scaling='weak', vs_baseline=None,
             dtype='f32 (bf16x3 split operands, f32 accumulate)' if split else 'f32',
             data='synthetic',
@@ -340,15 +415,16 @@ def bench_infer(args, device, rank):
                         '1000 proposals/img, per-class NMS + mask head' % (args.layers, batch, H, W),
                         arithmetic=ARITHMETIC_NOTE['split_bf16x3' if split else 'fp32'],
                         detections_per_image=n_det,
-                        executed_gemm_gflop_per_image=round(gflop / args.steps / batch, 1),
+                        executed_gemm_gflop_per_image=round(gflop / steps / batch, 1),
                         gemm_tflops=round(gflop / ms, 2)),
             roofline=dict(bound='mfma', kernel='conv_gemm_kernel (all instantiations)',
                           achieved=round(gflop / ms, 2), peak=infer_peak,
                           unit='TFLOP/s', frac=round(gflop / ms / infer_peak, 4),
                           peak_note=infer_note, traffic=None,
-                          kernels={k: dict(ms_per_step=round(v['total_ms'] / args.steps, 3),
-                                           launches_per_step=v['launches'] / args.steps)
-                                   for k, v in prof.items()})))
+                          kernels={k: dict(ms_per_step=round(v['total_ms'] / steps, 3),
+                                           launches_per_step=v['launches'] / steps)
+                                   for k, v in prof.items()}))
+    return None
 
 
 def free_port():
@@ -395,6 +471,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=3,
+                    help='how many times the timed region of --steps steps is run back to back; `value` '
+                         'is the median region, `repeats` reports all of them')
     ap.add_argument('--layers', type=int, default=50, choices=[50, 101])
     ap.add_argument('--batch', type=int, default=2, help='images per GPU')
     ap.add_argument('--height', type=int, default=800)
@@ -431,6 +510,9 @@ def main():
                     help='after the other measurements, time the same number of steps fed by the train '
                          "loop's input pipeline (tools/train_loop.py) over this many synthetic decoded "
                          'examples; 0 = skip')
+    ap.add_argument('--no-extra-workloads', dest='extra_workloads', action='store_false',
+                    help='skip the `r101` (BASELINE configs[3] per GPU) and `infer` (configs[4]) measurements '
+                         'that follow the headline on single-GPU ResNet-50 runs')
     ap.add_argument('--defer-wgrad', type=int, default=5,
                     help='number of res5 weight gradients (a.conv2, a.conv1, a.conv3, a.conv4, b1.conv2, ...) held back into the '
                          "next step's proposal window (single-GPU runs; 0 = off)")
@@ -481,7 +563,10 @@ def main():
     device = torch.device('cuda', local)
 
     if args.workload == 'infer':
-        return bench_infer(args, device, rank)
+        line = bench_infer(args, device, rank)
+        if line is not None:
+            emit_json(line)
+        return
 
     # examples/train_common.py:135-136 — the samplers consume the global NumPy stream
     import random
@@ -530,20 +615,35 @@ def main():
         lib.mrcnn_profile_enable(1 if args.profile_all else 2)
     if sync is not None:
         sync.exchange.timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # The headline region, `--repeats` times back to back (each: EXACTLY args.steps steps between
+    # two fences = barrier + device synchronise): the package runs these kernels at its power cap,
+    # so one 0.5 s sample moves with the box and its thermal state — `value` is the MEDIAN region,
+    # `repeats` keeps every region's time, and the power / shader clock sampled meanwhile go into
+    # `roofline`.
+    R = max(1, args.repeats)
+    region_s = []
+    smi = SmiSampler(local)
+    with smi:
+        for _ in range(R):
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step()
+            fence()
+            region_s.append(max_over_ranks(time.perf_counter() - t0))
+    smi_summary = smi.summary()
     prof = {} if args.no_profile else profile_summary()
     lib.mrcnn_profile_enable(0)
+    for v in prof.values():          # accumulated over R regions -> per region of args.steps steps
+        for k in ('total_ms', 'flops', 'bytes', 'launches'):
+            v[k] = v[k] / R
     bucket_times = None
     if sync is not None:
-        bucket_times = sync.exchange.bucket_times(len(sync.buckets.bounds))
+        bucket_times = [(ms / R, by / R, n) for ms, by, n in
+                        sync.exchange.bucket_times(len(sync.buckets.bounds))]
         sync.exchange.timing(False)
     n_rois = chain.last_targets['n_rois']
     loss_val = float(loss.item())
-    elapsed = max_over_ranks(elapsed)
+    elapsed = float(np.median(region_s))
     roi_iso = None
     if not args.no_profile and 'sample_roi_indices' in chain.last_targets:
         roi_iso = roi_align_isolated(chain, device)
@@ -752,6 +852,49 @@ def main():
                         step_waited_ms_per_batch=round(loop.host_seconds['wait'] / args.steps * 1e3, 2),
                         loss=round(float(loss_p.detach().item()), 5))
 
+    # ---- BASELINE configs[3] per GPU (ResNet101-C4, same batch) and configs[4] (inference) --------
+    # the other two single-GPU workloads of BASELINE.json, observed by whoever runs the default command
+    r101 = infer = None
+    if world == 1 and args.layers == 50 and args.extra_workloads:
+        model1, chain1, opt1, _ = build_trainer(101, device, 1, args.lr_batch or args.batch,
+                                                defer=args.defer_wgrad)
+        if args.prefetch_frozen:
+            chain1.next_imgs = imgs_d
+        for _ in range(max(2, args.warmup)):
+            opt1.update(chain1, imgs_d, bboxes, labels, masks, scales)
+        opt1.flush()
+        torch.cuda.synchronize()
+        lib.mrcnn_profile_enable(3) if not args.no_profile else None    # count flops only
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_1 = opt1.update(chain1, imgs_d, bboxes, labels, masks, scales)
+        opt1.flush()
+        torch.cuda.synchronize()
+        el_1 = time.perf_counter() - t0
+        prof_1 = {} if args.no_profile else profile_summary()
+        lib.mrcnn_profile_enable(0)
+        gf_1 = sum(v['flops'] for k, v in prof_1.items() if k.startswith('conv_gemm')) / 1e9
+        r101 = dict(value=round(args.steps * args.batch / el_1, 3), unit='images/sec',
+                    ms_per_step=round(el_1 / args.steps * 1e3, 3), steps=args.steps,
+                    workload='BASELINE configs[3], per-GPU part on 1 GPU: ResNet101-C4 Mask R-CNN train step '
+                             '(fwd+bwd+SGD), batch %dx%dx%d fp32, %d sampled RoIs/step'
+                             % (args.batch, args.height, args.width, chain1.last_targets['n_rois']),
+                    reference_gflop_per_image=TRAIN_GFLOP_PER_IMAGE[101],
+                    executed_gemm_gflop_per_image=round(gf_1 / args.steps / args.batch, 1) if gf_1 else None,
+                    step_tflops=round(gf_1 / 1e3 / el_1, 1) if gf_1 else None,
+                    loss=round(float(loss_1.item()), 5))
+        del model1, chain1, opt1
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        line = bench_infer(args, device, rank, steps=max(3, args.steps // 4), warmup=2)
+        infer = {k: line[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step')}
+        infer['workload'] = line['config']['workload']
+        infer['detections_per_image'] = line['config']['detections_per_image']
+        infer['gemm_tflops'] = line['config']['gemm_tflops']
+        infer['kernels'] = {k: v for k, v in sorted(line['roofline']['kernels'].items(),
+                                                    key=lambda kv: -kv[1]['ms_per_step'])[:8]}
+
     if rank == 0:
         global_batch = args.batch * world
         value = args.steps * global_batch / elapsed
@@ -779,6 +922,14 @@ def main():
                                            'per-frequency GEMMs)',
                             avg_launch_us=round(d['total_ms'] * 1e3 / d['launches'], 2),
                             launches_per_step=d['launches'] / args.steps,
+                            # package power and shader clock while the timed regions ran (median of
+                            # the samples; librocm_smi64), and the fraction against the peak at THAT
+                            # clock (peak scales with the shader clock; nominal 2400 MHz)
+                            power_w=smi_summary['power_w'], power_w_max=smi_summary['power_w_max'],
+                            sclk_mhz=smi_summary['sclk_mhz'], sclk_mhz_min=smi_summary['sclk_mhz_min'],
+                            smi_samples=smi_summary['samples'],
+                            frac_at_sustained_clock=round(ach / (peak * smi_summary['sclk_mhz'] / 2400.0), 4)
+                            if smi_summary['sclk_mhz'] else None,
                             # HBM-bound kernels of the step: algorithmic bytes / HIP-event time vs 8 TB/s
                             hbm_kernels={k: dict(gbs=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1),
                                                  frac_of_hbm_peak=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
@@ -831,7 +982,13 @@ def main():
             warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
             higher_is_better=True, scaling='weak', vs_baseline=None,
             dtype='f32' if main_arithmetic == 'fp32' else 'f32 (bf16x3 split operands, f32 accumulate)',
-            data='synthetic', config=config, roofline=roofline)
+            data='synthetic', config=config, roofline=roofline,
+            # every timed region (each args.steps steps between fences); `value` is the median one
+            repeats=dict(n=len(region_s), value_is='median',
+                         ms_per_step=[round(t / args.steps * 1e3, 3) for t in region_s],
+                         median=round(float(np.median(region_s)) / args.steps * 1e3, 3),
+                         min=round(min(region_s) / args.steps * 1e3, 3),
+                         max=round(max(region_s) / args.steps * 1e3, 3)))
         if roofline is not None and roofline['peak'] != FP32_MFMA_PEAK_TFLOPS:
             roofline['peak_note'] = ('split-operand arithmetic: peak = dense bf16 MFMA 2500 TFLOP/s / 6 '
                                      'products per fp32 multiply-add; achieved = nominal fp32 flops / '
@@ -854,6 +1011,10 @@ def main():
             out['direct_head_forward'] = wino_fwd
         if fp32_run is not None:
             out['fp32_mfma'] = fp32_run
+        if r101 is not None:
+            out['r101'] = r101
+        if infer is not None:
+            out['infer'] = infer
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         emit_json(out)

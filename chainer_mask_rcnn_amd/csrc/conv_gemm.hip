@@ -192,6 +192,11 @@ struct GemmParams {
     // (b / 256) x stagger_cycles shader cycles before its first load, so the phases interleave.
     // Placement only decides how well this works, never the result.
     int stagger_slots, stagger_cycles;
+    // N panels (FWD / DGRAD whole tiles): tiles are walked panel by panel — all M tiles of the first
+    // n_panel N-tiles, then of the next n_panel, ... — instead of N fastest over the whole width, so
+    // that the filter panel an XCD's resident workgroups sweep (n_panel x BN x K x 4 bytes) stays in
+    // its 4 MB L2 from one round of workgroups to the next (0: N fastest over the whole width).
+    int n_panel;
 };
 
 #ifdef MRCNN_GEMM_TRACE
@@ -454,8 +459,17 @@ conv_gemm_kernel(const GemmParams p)
         split = tile / (int)gridDim.x;
         tile -= split * (int)gridDim.x;
     }
-    const int m0 = p.m_lo + (tile / ntn) * BM;
-    const int n0 = (tile % ntn) * BN;
+    int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
+    if (MODE != WGRAD && !tail && p.n_panel > 0 && p.n_panel < ntn) {
+        const int ntm = (p.tail_splits > 0 ? p.tail_first : (int)gridDim.x) / ntn;
+        const int per_panel = ntm * p.n_panel;          // (every panel but the last is full)
+        const int panel = tile / per_panel, r = tile - panel * per_panel;
+        const int w = min(p.n_panel, ntn - panel * p.n_panel);
+        tile_m = r / w;
+        tile_n = panel * p.n_panel + (r - tile_m * w);
+    }
+    const int m0 = p.m_lo + tile_m * BM;
+    const int n0 = tile_n * BN;
 
     // ---------------- per-thread gather state -----------------------------------
     constexpr int KC_C4 = BK / 4, KC_RPP = 256 / KC_C4;   // float4 per row, rows per pass
@@ -1522,6 +1536,9 @@ int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM 
 int g_split_bf16 = 3;  // mrcnn_set_tuning("split_bf16"): bit 0 = 128x128 kernels, bit 1 = 64x64 forward form on the
                        // split-operand arithmetic (see SPLIT; the default since round 4), 0 = fp32 MFMA everywhere
 int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal start-up stagger; 0 = off)
+int g_n_panel = 0;    // mrcnn_set_tuning("n_panel"): GemmParams::n_panel for the 128x128 forward-form launches;
+                      // 0 = off, -1 = by filter size (panels of <= g_n_panel_kb KB), k > 0 = k N-tiles
+int g_n_panel_kb = 2048;
 int g_stagger_min_rounds = 2;
 
 template <int TM, int TN, int MODE, bool MASKED>
@@ -1839,6 +1856,13 @@ int launch(const GemmParams &p0, int splits, hipStream_t s)
             }
         }
         const int rows_main = (int)std::min<int64_t>(p.M, main_tiles_m * 128);
+        if (g_n_panel > 0) {
+            p.n_panel = g_n_panel;
+        } else if (g_n_panel < 0) {
+            const int64_t tile_col_bytes = 128ll * p.R * p.S * p.Kc * 4;      // one N-tile of the filter
+            if (tn * tile_col_bytes > (int64_t)g_n_panel_kb * 1024 * 5 / 4)
+                p.n_panel = (int)std::max<int64_t>(1, (int64_t)g_n_panel_kb * 1024 / tile_col_bytes);
+        }
         if (!(splits == 1 && launch_fused_tail<2, 2, MODE>(p, rows_main, s))) {
             launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
             if (rows_main < p.M) launch_remainder<MODE>(p, rows_main, s);
@@ -1977,6 +2001,14 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "stagger") == 0) {
         g_stagger = value;
+        return 0;
+    }
+    if (strcmp(name, "n_panel") == 0) {
+        g_n_panel = value;
+        return 0;
+    }
+    if (strcmp(name, "n_panel_kb") == 0) {
+        g_n_panel_kb = value;
         return 0;
     }
     if (strcmp(name, "stagger_min_rounds") == 0) {

@@ -540,9 +540,9 @@ _wino_u_cache = {}
 # ---- arithmetic of the convolution GEMMs ----------------------------------------------------
 # 'split_bf16x3' (default since round 4): every fp32 operand element is split EXACTLY into three
 # bf16 values (8 + 8 + 8 significand bits) while it is staged, and a K step runs six bf16 MFMAs
-# (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) with fp32 accumulation; the dropped cross terms are
-# <= 2^-24 of a product each — the size of ONE fp32 rounding — so the result carries the error of an
-# fp32 GEMM (tests/test_gpu_split_bf16.py measures it against float64 next to the fp32-MFMA
+# (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) with fp32 accumulation; the three dropped cross
+# terms (mid*lo, lo*mid, lo*lo) are <= 2^-24 of a product each, <= 2^-23 in total — the size of ONE
+# fp32 rounding — so the result carries the error of an fp32 GEMM (tests/test_gpu_split_bf16.py measures it against float64 next to the fp32-MFMA
 # kernels': smaller on every case) at 2.7x the matrix-pipe rate (gfx950 has no TF32 / xf32 and its
 # fp32 MFMA runs at 1/16 of the bf16 rate).  Covers the forward-form kernels (forward, stride-1 data
 # gradient, the Winograd per-frequency GEMMs) and the 128x128 weight gradient; the strided data
@@ -554,7 +554,18 @@ GEMM_ARITHMETIC = DEFAULT_GEMM_ARITHMETIC
 
 
 def set_gemm_arithmetic(kind):
-    """Select 'split_bf16x3' (default) or 'fp32' for the convolution GEMM kernels (process-wide)."""
+    """Select 'split_bf16x3' (default) or 'fp32' for the convolution GEMM kernels (process-wide).
+
+    Operand range of 'split_bf16x3' (bf16 has fp32's exponent range, so nothing is rescaled):
+    * finite elements up to bf16's largest value (3.3895e38; |x| <= 0.99 FLT_MAX is safe) split
+      exactly, whatever mix of magnitudes a K row or a tile holds (per element, no shared exponent);
+    * an element that is NaN, +-inf or finite but beyond that value (it rounds to +-inf in bf16)
+      makes EVERY output that reads it NaN — fp32 multiplication would give +-inf for the
+      infinities; outputs that do not read it are unaffected;
+    * parts of an element below 2^-126 may be flushed to zero: the error of an element's
+      representation is < 3 x 2^-126 in absolute terms (relative to elements below ~1e-33 that is
+      more than an fp32 rounding).
+    Asserted by tests/test_gpu_split_bf16.py (device) and tests/test_split_arithmetic_cpu.py (model)."""
     global GEMM_ARITHMETIC
     if kind not in ('fp32', 'split_bf16x3'):
         raise ValueError("gemm arithmetic must be 'fp32' or 'split_bf16x3', got %r" % (kind,))

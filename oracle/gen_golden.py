@@ -516,6 +516,44 @@ TRAIN_STEP_CFG = dict(n_layers=50, H=160, W=224, batch=2, n_gt=3, n_sample=32, i
                                                    n_train_post_nms=100))
 
 
+def train_step_margins(np_step, cfg):
+    """Smallest ReLU margin (np_step.RELU_MARGINS) of the fixture step under ``cfg``: (value, site)."""
+    P = np_step.synthetic_params(cfg['n_layers'], seed=cfg['param_seed'])
+    imgs, bboxes, labels, masks, scales = np_step.synthetic_inputs(
+        cfg['input_seed'], cfg['batch'], cfg['H'], cfg['W'], n_gt=cfg['n_gt'], scale=1.0)
+    np.random.seed(cfg['np_random_seed'])
+    np_step.RELU_MARGINS = m = {}
+    try:
+        np_step.train_step(P, imgs, bboxes, labels, masks, scales, n_layers=cfg['n_layers'],
+                           n_sample=cfg['n_sample'], backward=False,
+                           proposal_creator_params=cfg['proposal_creator_params'])
+    finally:
+        np_step.RELU_MARGINS = None
+    site = min(m, key=m.get)
+    return m[site], site
+
+
+def search_train_step_seeds(n=48):
+    """`python oracle/gen_golden.py --search-train-step-seeds [n]`: how TRAIN_STEP_CFG's seeds were
+    chosen.  The fixture is compared ENTRY BY ENTRY (1e-4 of a tensor's scale) with other fp32-class
+    implementations, which is well posed only if no ReLU with a backward sits on a pre-activation
+    within rounding of zero (one flipped decision moves a patch of every gradient below it by up to
+    1e-3).  fp32 rounding of these layers is ~1e-7 .. 1e-6 of the site's scale; among ~3e6 units the
+    typical smallest margin is of that order, so the seeds are searched for the LARGEST smallest
+    margin.  Prints every candidate; edit TRAIN_STEP_CFG by hand and regenerate."""
+    from oracle import np_step
+    rows = []
+    for k in range(n):
+        cfg = dict(TRAIN_STEP_CFG, input_seed=1 + k, np_random_seed=11 + k)
+        v, site = train_step_margins(np_step, cfg)
+        rows.append((v, cfg['input_seed'], cfg['np_random_seed'], site))
+        print('input_seed %3d np_random_seed %3d: smallest ReLU margin %.3e at %s'
+              % (cfg['input_seed'], cfg['np_random_seed'], v, site), flush=True)
+    rows.sort(reverse=True)
+    print('best:', rows[:5])
+    return rows
+
+
 def train_step_fixture(np_step):
     c = TRAIN_STEP_CFG
     P = np_step.synthetic_params(c['n_layers'], seed=c['param_seed'])
@@ -545,4 +583,7 @@ def train_step_fixture(np_step):
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == '--search-train-step-seeds':
+        search_train_step_seeds(int(sys.argv[2]) if len(sys.argv) > 2 else 48)
+    else:
+        main()

@@ -43,24 +43,60 @@ def _aff(x, P, pre):
     return np_ref.affine_channel_2d_fwd(x, P[pre + '.W'], P[pre + '.b'])
 
 
+# Diagnostic of the fixture generator (oracle/gen_golden.py: choosing the seeds of
+# tests/golden/train_step.npz): when set to a dict, every ReLU that has a BACKWARD (res3 .. res5,
+# the RPN's conv1, deconv6) records, per site, the smallest |pre-activation| relative to the
+# site's largest.  A unit whose pre-activation lies within fp32 rounding of zero takes its
+# gradient mask from the rounding; a fixture whose smallest margin is far above that is one on
+# which every fp32-class implementation takes the same decisions.  Never changes a result.
+RELU_MARGINS = None
+# Decision-conditioned evaluation (tests/test_gpu_step_golden.py): RELU_PRE, when a dict, receives
+# every such site's pre-activation array; RELU_FORCE, when a dict {site: bool array}, REPLACES the
+# site's decisions (p > 0) in the forward AND in the backward's gradient mask — the step "given the
+# decisions" of another implementation, which is the well-posed form of an entrywise gradient
+# comparison between two fp32-class implementations.  Sites: '<block>.1' / '.2' / '.3' (the three
+# ReLUs of a bottleneck), 'rpn.conv1', 'head.deconv6'.  Unset (the default), nothing changes.
+RELU_PRE = None
+RELU_FORCE = None
+
+
+def _relu(p, site):
+    """-> (relu(p), decisions).  The decisions are (p > 0) unless RELU_FORCE overrides the site."""
+    if RELU_MARGINS is not None:
+        a = np.abs(p)
+        nz = a[a > 0]              # (exact zeros — structural — are zero in every implementation)
+        if nz.size:
+            RELU_MARGINS[site] = min(RELU_MARGINS.get(site, np.inf), float(nz.min() / a.max()))
+    if RELU_PRE is not None:
+        RELU_PRE[site] = p
+    if RELU_FORCE is not None and site in RELU_FORCE:
+        m = np.asarray(RELU_FORCE[site], bool)
+        assert m.shape == p.shape, (site, m.shape, p.shape)
+        return np.where(m, p, p.dtype.type(0)), m
+    y = np.maximum(p, 0)
+    return y, y > 0
+
+
 def bottleneck_fwd(x, P, pre, stride, proj):
     """chainer BottleneckA (proj) / BottleneckB."""
-    h1 = np.maximum(_aff(np_ref.conv2d_fwd(x, P[pre + '.conv1.W'], None, stride, 0), P, pre + '.bn1'), 0)
-    h2 = np.maximum(_aff(np_ref.conv2d_fwd(h1, P[pre + '.conv2.W'], None, 1, 1), P, pre + '.bn2'), 0)
+    trainable = not pre.startswith('extractor.res2')          # (res2 is below freeze_at: no backward)
+    relu = _relu if trainable else (lambda p, site: (np.maximum(p, 0), None))
+    h1, m1 = relu(_aff(np_ref.conv2d_fwd(x, P[pre + '.conv1.W'], None, stride, 0), P, pre + '.bn1'), pre + '.1')
+    h2, m2 = relu(_aff(np_ref.conv2d_fwd(h1, P[pre + '.conv2.W'], None, 1, 1), P, pre + '.bn2'), pre + '.2')
     p3 = _aff(np_ref.conv2d_fwd(h2, P[pre + '.conv3.W']), P, pre + '.bn3')
     sc = _aff(np_ref.conv2d_fwd(x, P[pre + '.conv4.W'], None, stride, 0), P, pre + '.bn4') if proj else x
-    y = np.maximum(p3 + sc, 0)
-    return y, (x, h1, h2, y, stride, proj)
+    y, m3 = relu(p3 + sc, pre + '.3')
+    return y, (x, h1, h2, y, stride, proj, m1, m2, m3)
 
 
 def bottleneck_bwd(gy, cache, P, pre, grads, need_gx=True):
-    x, h1, h2, y, stride, proj = cache
+    x, h1, h2, y, stride, proj, m1, m2, m3 = cache      # m*: the ReLU decisions ((h > 0) unless forced)
     ch = lambda v: v[None, :, None, None]
-    g = gy * (y > 0)
+    g = gy * m3
     gh2, grads[pre + '.conv3.W'], _ = np_ref.conv2d_bwd(h2, P[pre + '.conv3.W'], g * ch(P[pre + '.bn3.W']))
-    g2 = gh2 * (h2 > 0) * ch(P[pre + '.bn2.W'])
+    g2 = gh2 * m2 * ch(P[pre + '.bn2.W'])
     gh1, grads[pre + '.conv2.W'], _ = np_ref.conv2d_bwd(h1, P[pre + '.conv2.W'], g2, 1, 1)
-    g1 = gh1 * (h1 > 0) * ch(P[pre + '.bn1.W'])
+    g1 = gh1 * m1 * ch(P[pre + '.bn1.W'])
     gx, grads[pre + '.conv1.W'], _ = np_ref.conv2d_bwd(x, P[pre + '.conv1.W'], g1, stride, 0,
                                                         need_gx=need_gx)
     if proj:
@@ -121,7 +157,7 @@ def train_step(P, imgs, bboxes, labels, masks, scales, n_layers=50, n_class=81,
     hh, ww = feat.shape[2:]
     anchor = np_ref.enumerate_shifted_anchor(
         np_ref.generate_anchor_base(16, ratios, anchor_scales), 16, hh, ww)
-    rpn_h = np.maximum(np_ref.conv2d_fwd(feat, P['rpn.conv1.W'], P['rpn.conv1.b'], 1, 1), 0)
+    rpn_h, m_rpn = _relu(np_ref.conv2d_fwd(feat, P['rpn.conv1.W'], P['rpn.conv1.b'], 1, 1), 'rpn.conv1')
     rpn_out = np_ref.conv2d_fwd(rpn_h, P['rpn.loc_score.W'], P['rpn.loc_score.b'])
     nhwc = rpn_out.transpose(0, 2, 3, 1)
     rpn_locs = np.ascontiguousarray(nhwc[..., :4 * A]).reshape(N, -1, 4)
@@ -163,7 +199,7 @@ def train_step(P, imgs, bboxes, labels, masks, scales, n_layers=50, n_class=81,
     fc = np_ref.linear_fwd(pool5, Wfc, bfc)
     roi_cls_locs, roi_scores = fc[:, :4 * n_class], fc[:, 4 * n_class:]
     dpre = np_ref.deconv2x2s2_fwd(res5, P['head.deconv6.W'], P['head.deconv6.b'])
-    d6 = np.maximum(dpre, 0)
+    d6, m_d6 = _relu(dpre, 'head.deconv6')
     roi_masks = np_ref.conv2d_fwd(d6, P['head.mask.W'], P['head.mask.b'])
     mark('head')
     # ---- losses (:163-181) ----
@@ -192,7 +228,7 @@ def train_step(P, imgs, bboxes, labels, masks, scales, n_layers=50, n_class=81,
     g_masks_out[ar, gt_roi_labels - 1] = g_sel_mask
     g_d6, G['head.mask.W'], G['head.mask.b'] = np_ref.conv2d_bwd(d6, P['head.mask.W'], g_masks_out)
     g_res5, G['head.deconv6.W'], G['head.deconv6.b'] = np_ref.deconv2x2s2_bwd(
-        res5, P['head.deconv6.W'], g_d6 * (dpre > 0))
+        res5, P['head.deconv6.W'], g_d6 * m_d6)
     g_fc = np.zeros((R, P['head.cls_loc_score.W'].shape[0]), f32)
     g_cls = np.zeros((R, n_class, 4), f32)
     g_cls[ar, gt_roi_labels] = g_sel_loc
@@ -213,7 +249,7 @@ def train_step(P, imgs, bboxes, labels, masks, scales, n_layers=50, n_class=81,
     g_rpn_h, G['rpn.loc_score.W'], G['rpn.loc_score.b'] = np_ref.conv2d_bwd(
         rpn_h, P['rpn.loc_score.W'], g_out)
     g_f2, G['rpn.conv1.W'], G['rpn.conv1.b'] = np_ref.conv2d_bwd(
-        feat, P['rpn.conv1.W'], g_rpn_h * (rpn_h > 0), 1, 1)
+        feat, P['rpn.conv1.W'], g_rpn_h * m_rpn, 1, 1)
     g_feat = g_feat + g_f2
     mark('rpn backward')
     g_res3 = stage_bwd(g_feat, c_res4, P, 'extractor.res4', G)

@@ -3,7 +3,19 @@ tests/golden/train_step.npz ("the build's CPU restatement 
 synthetic image with fixed weights -> 6 loss values + selected RoI indices, committed, then
 required bit-exact for integers / 1e-4 for floats from the HIP path").  Weights and inputs are
 regenerated from the fixture's seeds (oracle/np_step.synthetic_*), the global np.random stream
-is seeded as the generator did."""
+is seeded as the generator did.
+
+Gradients ENTRY BY ENTRY.  Two fp32-class implementations of this step agree on every entry only if
+they take the same ReLU decisions, and among the ~4e7 units with a backward a handful sit within
+rounding of zero on ANY seed (tools/pick_step_fixture_seeds.py: 24 of 24 seed pairs have at least one
+tensor beyond 1e-4 on BOTH arithmetics) — one flipped decision moves a patch of every gradient below
+it by 1e-4 .. 1e-2 of its scale.  The entrywise statement is therefore made in its well-posed form,
+for EVERY trainable tensor and with no exemption, on both arithmetics:
+  (1) the HIP step's ReLU decisions differ from the oracle's only at units whose oracle
+      pre-activation lies within 1e-4 of the site's scale of zero, fewer than 1 in 100 000 of them;
+  (2) GIVEN the decisions (the oracle step re-evaluated with the HIP step's decisions,
+      oracle/np_step.RELU_FORCE), every gradient entry and the six losses agree to 1e-4.
+When no decision differs, (2) is the comparison with the committed fixture itself."""
 import os
 
 import numpy as np
@@ -25,8 +37,8 @@ def arithmetic(request):
     C_.set_gemm_arithmetic(C_.DEFAULT_GEMM_ARITHMETIC)
 
 
-def test_hip_train_step_matches_fixture(dev, golden_dir, arithmetic):
-    d = np.load(os.path.join(golden_dir, 'train_step.npz'))
+def _hip_step(dev, with_tap):
+    from chainer_mask_rcnn_amd.functions import conv as C_
     P = np_step.synthetic_params(C['n_layers'], seed=C['param_seed'])
     imgs, bboxes, labels, masks, scales = np_step.synthetic_inputs(
         C['input_seed'], C['batch'], C['H'], C['W'], n_gt=C['n_gt'], scale=1.0)
@@ -42,9 +54,55 @@ def test_hip_train_step_matches_fixture(dev, golden_dir, arithmetic):
             assert tuple(p.shape) == P[name].shape, name
             p.copy_(torch.from_numpy(P[name]))
     np.random.seed(C['np_random_seed'])
-    loss = chain(torch.tensor(imgs, device=dev), bboxes, labels, masks, list(scales))
+    tap = [] if with_tap else None
+    C_.RELU_TAP = tap
+    try:
+        loss = chain(torch.tensor(imgs, device=dev), bboxes, labels, masks, list(scales))
+    finally:
+        C_.RELU_TAP = None
+    after = int(np.random.randint(0, 2 ** 31 - 1))       # position of the global stream
     loss.backward()
     torch.cuda.synchronize()
+    return model, chain, tap, after, (P, imgs, bboxes, labels, masks, scales)
+
+
+def _hip_decisions(tap):
+    """RELU_TAP entries in call order -> {oracle site: bool NCHW array} for the sites with a backward."""
+    names = []
+    for stage, n in zip(('extractor.res2', 'extractor.res3', 'extractor.res4'), np_step.BLOCKS[C['n_layers']]):
+        names += ['%s.%s' % (stage, 'a' if i == 0 else 'b%d' % i) for i in range(n)]
+    names += ['rpn.conv1'] + ['head.res5.%s' % b for b in ('a', 'b1', 'b2')] + ['head.deconv6']
+    assert len(tap) == len(names), (len(tap), len(names))
+    out = {}
+    for name, (kind, t) in zip(names, tap):
+        if name.startswith('extractor.res2'):
+            continue                                       # below freeze_at: no backward
+        if kind == 'block':
+            for sub, a in zip(('1', '2', '3'), t):
+                out['%s.%s' % (name, sub)] = (a > 0).cpu().numpy()
+        else:
+            out[name] = (t > 0).cpu().numpy()
+    return out
+
+
+_ORACLE_FREE = {}
+
+
+def _oracle_step(inputs, force=None, record=None):
+    P, imgs, bboxes, labels, masks, scales = inputs
+    np.random.seed(C['np_random_seed'])
+    np_step.RELU_FORCE, np_step.RELU_PRE = force, record
+    try:
+        return np_step.train_step(P, imgs, bboxes, labels, masks, scales, n_layers=C['n_layers'],
+                                  n_sample=C['n_sample'],
+                                  proposal_creator_params=C['proposal_creator_params'])
+    finally:
+        np_step.RELU_FORCE = np_step.RELU_PRE = None
+
+
+def test_hip_train_step_matches_fixture(dev, golden_dir, arithmetic):
+    d = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    model, chain, tap, rng_after, inputs = _hip_step(dev, with_tap=True)
     # integers: the proposals (decode, top-k order, NMS keep list), the sampled RoIs and their
     # labels, and the position of the global np.random stream afterwards
     # (the box COORDINATES are fp32 results of the RPN convolutions: within 1e-4 relative)
@@ -52,39 +110,59 @@ def test_hip_train_step_matches_fixture(dev, golden_dir, arithmetic):
     assert np.array_equal(t['gt_roi_labels'].cpu().numpy(), d['gt_roi_labels'])
     assert np.array_equal(t['gt_roi_masks'].cpu().numpy(), d['gt_roi_masks'].astype(np.int32))
     assert np.array_equal(t['gt_rpn_labels'].cpu().numpy(), d['gt_rpn_labels'].astype(np.int32))
-    assert int(np.random.randint(0, 2 ** 31 - 1)) == int(d['np_random_after'])
+    assert rng_after == int(d['np_random_after'])
     np.testing.assert_allclose(t['sample_rois'].cpu().numpy(), d['sample_rois'], rtol=1e-4, atol=1e-3)
     # floats: the six reported scalars
     rep = {k: float(v) for k, v in chain.report.items()}
     for k, v in zip(d['loss_names'], d['loss_values']):
         assert abs(rep[str(k)] - v) <= 1e-4 * max(abs(v), 1e-3), (k, rep[str(k)], v)
-    # gradients: norms of every trainable tensor, and a few small tensors element by element
-    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    # gradients: the L2 norm of every trainable tensor against the fixture
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
     for k, l2, mx in zip(d['grad_names'], d['grad_l2'], d['grad_absmax']):
-        g = grads[str(k)].detach().double()
-        assert abs(float(g.norm()) - l2) <= 1e-4 * l2 + 1e-12, (k, float(g.norm()), l2)
-    for key in d.files:
-        if key.startswith('grad/'):
-            ref = d[key]
-            got = grads[key[5:]].detach().cpu().numpy()
-            scale = np.abs(ref).max()
-            err = np.abs(got - ref) / scale
-            print('%-34s %s: max |got - fixture| = %.2e of the tensor scale, %.4f %% of the entries '
-                  'beyond 1e-4' % (key, arithmetic, err.max(), 100. * (err > 1e-4).mean()))
-            if key == 'grad/extractor.res3.a.conv1.W' and arithmetic != 'fp32':
-                # The deepest trainable tensor, compared ENTRY BY ENTRY with another fp32-class
-                # implementation (the fixture is the NumPy oracle's fp32 step): a unit whose
-                # pre-activation lies within rounding of zero takes its ReLU decision from the
-                # rounding, and one flipped decision in res3 / res4 moves a patch of every
-                # gradient below it by 1e-4 .. 1e-3 of its scale (README "Parity criteria",
-                # DESIGN.md section 4.3, profiles/r03_seed_study.json: true of any two fp32
-                # implementations, torch's CPU kernels included).  The fp32-MFMA kernels happen to
-                # agree with the oracle on every decision of this fixture (8e-6 here); the
-                # split-operand kernels — closer to float64 per op, tests/test_gpu_split_bf16.py —
-                # differ on one.  The well-posed statement for them (decisions against float64,
-                # then every entry given the decisions, 1e-4) is tests/test_gpu_model.py run under
-                # this arithmetic by tests/test_gpu_split_bf16.py; here: rms within 1e-4 of the
-                # scale, no entry beyond 2e-3, and the tensor's L2 norm within 1e-4 (above).
-                assert np.sqrt((err ** 2).mean()) <= 1e-4 and err.max() <= 2e-3, key
-            else:
-                assert err.max() <= 1e-4, key
+        g = np.sqrt(np.sum(grads[str(k)].astype(np.float64) ** 2))
+        assert abs(g - l2) <= 1e-4 * l2 + 1e-12, (k, g, l2)
+
+    # (1) ReLU decisions against the oracle's own (one free oracle run, shared by both arithmetics)
+    hip = _hip_decisions(tap)
+    del tap[:]
+    if 'out' not in _ORACLE_FREE:
+        pre = {}
+        _ORACLE_FREE['out'] = _oracle_step(inputs, record=pre)
+        _ORACLE_FREE['pre'] = pre
+    free, pre = _ORACLE_FREE['out'], _ORACLE_FREE['pre']
+    assert sorted(hip) == sorted(pre), (sorted(set(hip) ^ set(pre)))
+    n_units = n_diff = 0
+    worst = 0.
+    for site, m in hip.items():
+        p_ = pre[site]
+        assert m.shape == p_.shape, (site, m.shape, p_.shape)
+        diff = m != (p_ > 0)
+        n_units += m.size
+        n_diff += int(diff.sum())
+        if diff.any():
+            w = float(np.abs(p_[diff]).max() / np.abs(p_).max())
+            worst = max(worst, w)
+            assert w <= 1e-4, (site, w)
+    print('%s: %d of %d ReLU decisions differ from the oracle\'s, all within %.1e of the site scale of zero'
+          % (arithmetic, n_diff, n_units, worst))
+    assert n_diff <= 1e-5 * n_units
+
+    # (2) every gradient entry, given the decisions
+    if n_diff == 0:
+        ref, what = free, 'the fixture step'
+        for key in d.files:                 # the committed arrays themselves
+            if key.startswith('grad/'):
+                scale = np.abs(d[key]).max()
+                assert np.abs(grads[key[5:]] - d[key]).max() <= 1e-4 * scale, key
+    else:
+        ref, what = _oracle_step(inputs, force=hip), 'the oracle step given the HIP decisions'
+        for k, v in ref['losses'].items():
+            assert abs(rep[k] - v) <= 1e-4 * max(abs(v), 1e-3), (k, rep[k], v)
+    worst, worst_name = 0., None
+    for name, g_ref in ref['grads'].items():
+        err = float(np.abs(grads[name] - g_ref).max() / max(np.abs(g_ref).max(), 1e-30))
+        if err > worst:
+            worst, worst_name = err, name
+    print('%s: worst gradient entry vs %s: %.2e of the tensor scale (%s), %d tensors'
+          % (arithmetic, what, worst, worst_name, len(ref['grads'])))
+    assert worst <= 1e-4, (worst_name, worst)

@@ -227,3 +227,110 @@ def test_data_parallel_grad_sync_gloo_world2():
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+# ---- rehearsal of the 8-rank launch on the REAL ResNet50-C4 arena --------------------------------
+# /root/reference/examples/train_common.py:96-104,160-190: one process per GPU, rank-0 parameters
+# broadcast, gradients averaged before the update.  The driver's 8-GPU run is the first time the
+# data-parallel path runs at world size 8; this is the same code — bench.build_trainer (model,
+# frozen set, deferred res5 gradients, 16 MB buckets), DataParallelGradSync.attach, the in-backward
+# polling, finish(), reduce_deferred — at world size 8 over gloo, with the exchange the only stand-in
+# (TorchDistExchange instead of RCCL behind the C ABI; same interface).
+def _rehearsal_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'] = str(rank)
+    os.environ['WORLD_SIZE'] = str(world)
+    os.environ['LOCAL_RANK'] = str(rank)
+    torch.set_num_threads(1)
+    import zlib
+    import bench
+    from chainer_mask_rcnn_amd import parallel
+    r, w, _ = parallel.init_from_env(backend='gloo')
+    failed = []
+
+    def ck(k, cond):
+        if not cond:
+            failed.append(k)
+    ck(0, (r, w) == (rank, world))
+    torch.manual_seed(100 + rank)                      # every rank starts from DIFFERENT weights
+    cpu = torch.device('cpu')
+    model, chain, opt, sync = bench.build_trainer(50, cpu, world, 2 * world, bucket_bytes=16 << 20, defer=5)
+    ck(1, sync is not None and isinstance(sync.exchange, parallel.TorchDistExchange))
+    opt._build()                                       # arena + attach: broadcast, bucket plan, hooks
+    a = opt.arena
+
+    def checksum():
+        h = 0
+        for _, t in sorted(list(chain.named_parameters()) + list(chain.named_buffers()), key=lambda kv: kv[0]):
+            h = zlib.crc32(t.detach().contiguous().numpy().tobytes(), h)
+        return h
+    sums = [None] * world
+    dist.all_gather_object(sums, checksum())
+    ck(2, len(set(sums)) == 1)                    # rank 0's parameters AND buffers everywhere
+    # the plan: identical on every rank, 143 MB of gradients in ~16 MB buckets cut at block
+    # boundaries, the five held-back res5 filters in none of them, everything else in exactly one
+    plans = [None] * world
+    dist.all_gather_object(plans, (sync.bucket_params, sync.buckets.bounds, a.size))
+    ck(3, all(p == plans[0] for p in plans))
+    held = set(id(p) for p in opt.deferred_params)
+    ck(4, len(held) == 5)
+    covered = []
+    for lo, hi in sync.bucket_params:
+        covered += list(range(lo, hi + 1))
+    ck(5, len(covered) == len(set(covered)))
+    ck(6, all((i in set(covered)) != (id(p) in held) for i, p in enumerate(a.params)))
+    mb = [(e - s) * 4 / 2 ** 20 for s, e in sync.buckets.bounds]
+    ck(7, 130 < a.size * 4 / 2 ** 20 < 160 and 4 <= len(mb) <= 12)
+    # (only the bucket that ends a run of consecutive non-held parameters may be smaller than 16 MB)
+    from chainer_mask_rcnn_amd.optimizers import _runs
+    n_runs = len(_runs([id(p) not in held for p in a.params]))
+    ck(8, sum(1 for m in mb if m < 16.0) <= n_runs and max(mb) < 64.0)
+    from chainer_mask_rcnn_amd.models.resnet_extractor import BuildingBlock
+    blocks = [m for m in chain.modules() if isinstance(m, BuildingBlock)]
+    ck(9, len(blocks) == 4 and all(m.grad_poll == sync.poll for m in blocks))
+    ck(10, chain.features_grad_hook is not None)
+    # a backward in arena order (= the order backward produces gradients), polled as the fused stage
+    # nodes do (after every few parameters); rank r contributes r + 1 everywhere
+    log = []
+    real = sync.exchange.allreduce_async
+    sync.exchange.allreduce_async = lambda t, b=0: (log.append(b), real(t, b))[1]
+    first_launch_at = None
+    for i, p in enumerate(a.params):
+        assert a.claim(p)
+        p.grad.fill_(float(rank + 1))
+        if i % 3 == 2:
+            sync.poll()
+            if first_launch_at is None and log:
+                first_launch_at = i
+    ck(11, first_launch_at is not None and first_launch_at < len(a.params) // 2)   # overlaps backward
+    scale = sync.finish()
+    ck(12, log == list(range(len(mb))) and abs(scale * world - 1.0) < 1e-12)
+    total = float(sum(range(1, world + 1)))
+    for i, p in enumerate(a.params):
+        want = float(rank + 1) if id(p) in held else total
+        ck(13, bool((p.grad == want).all()))
+    # the held-back slices: reduced on their own, as MomentumSGD.launch_pending does
+    runs = [a.slice_bounds(f, l) for f, l in _runs([id(p) in held for p in a.params])]
+    sync.reduce_deferred([a.grads[lo:hi] for lo, hi in runs])
+    ck(14, all(bool((p.grad == total).all()) for p in a.params))
+    q.put((rank, failed, len(mb)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_rehearsal_on_the_resnet50_arena():
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rehearsal_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(world)]
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] == [] for r in res), res      # (numbers of the failed checks per rank)
+    assert len(set(r[2] for r in res)) == 1

@@ -8,8 +8,8 @@ DESIGN.md section 4.4), modelled in NumPy — no GPU: the statements the default
     one fp32 rounding of the product.
 (3) A K-long dot product evaluated that way (16 products summed per MFMA, fp32 accumulator, smallest
     terms first) is at least as close to float64 as a plain fp32 multiply-add loop.
-The plane image layout of include/mrcnn_hip.h ("operand planes") is restated as well, so that the
-GPU test's decode (tests/test_gpu_split_bf16.py) has a CPU counterpart."""
+(4) Outside the finite bf16 range the split turns an element into NaN; in the denormal range its
+    error is bounded in absolute terms (2^-126 per flushed part)."""
 import numpy as np
 
 
@@ -105,24 +105,32 @@ def test_split_dot_product_is_at_least_as_close_to_float64_as_an_fp32_loop():
     assert max(err_s) <= 1.5 * max(err_f) and max(err_s) <= 3e-6      # far inside the north star's 1e-4
 
 
-def test_plane_image_layout():
-    """6 bytes per element: per row, per 32-element chunk, hi | mid | lo as 32 bf16 each."""
-    rng = np.random.RandomState(3)
-    rows, L = 5, 96
-    x = rng.standard_normal((rows, L)).astype(np.float32)
+def test_non_finite_and_overflow_semantics_of_the_split():
+    """What the kernel's split3 does outside the finite bf16 range (documented next to
+    functions.conv.set_gemm_arithmetic, asserted on the device by tests/test_gpu_split_bf16.py):
+    an infinite element, and a finite one that rounds to infinity in bf16 (|x| above bf16's largest
+    value 3.3895e38 by more than half a bf16 ulp), has hi = +-inf and a NaN among mid / lo: every
+    output that reads the element is NaN where fp32 arithmetic would give +-inf.  Everything up to
+    0.99 FLT_MAX splits exactly."""
+    with np.errstate(invalid='ignore', over='ignore'):
+        for bad in (np.inf, -np.inf, np.nan, np.float32(3.4e38), -np.finfo(np.float32).max):
+            hi, mid, lo = split3(np.float32([bad]))
+            # (a finite overflow has mid = x - inf = -+inf and lo = NaN; the products hi*b and mid*b
+            # then cancel to NaN in the accumulator just the same)
+            assert not np.isfinite(hi[0]) and (np.isnan(mid[0]) or np.isnan(lo[0]))
+    x = np.float32([0.9, -0.99, 0.5]) * np.finfo(np.float32).max
     hi, mid, lo = split3(x)
-    img = np.zeros((rows, L // 32, 3, 32), np.uint16)
-    for q, part in enumerate((hi, mid, lo)):
-        img[:, :, q, :] = (part.view(np.uint32) >> 16).astype(np.uint16).reshape(rows, L // 32, 32)
-    raw = img.tobytes()
-    assert len(raw) == rows * L * 6
-    # plane_off(row, col, q) of conv_gemm.hip
-    def off(r, c, q):
-        return r * L * 6 + (c >> 5) * 192 + q * 64 + (c & 31) * 2
-    for r, c in ((0, 0), (1, 31), (2, 32), (4, 95)):
-        for q, part in enumerate((hi, mid, lo)):
-            v = np.frombuffer(raw[off(r, c, q):off(r, c, q) + 2], np.uint16)[0]
-            assert v == (part[r, c].view(np.uint32) >> 16)
-    back = (img.astype(np.uint32) << 16).view(np.float32)
-    assert np.array_equal((back[:, :, 0].astype(np.float64) + back[:, :, 1] + back[:, :, 2])
-                          .reshape(rows, L).astype(np.float32), x)
+    assert np.all(np.isfinite(hi)) and np.array_equal(hi.astype(np.float64) + mid + lo, x.astype(np.float64))
+
+
+def test_denormal_range_error_is_absolute_not_relative():
+    """Parts of the split below the smallest normal fp32 / bf16 value 2^-126 may be flushed by the
+    bf16 conversion and the matrix pipe: the representation error of an element is then < 2^-126 in
+    ABSOLUTE terms whatever is flushed (relative to a tiny element it can be large: below 3e-36 the
+    mid part is denormal too).  Modelled here as flush-to-zero of every denormal part."""
+    rng = np.random.RandomState(5)
+    x = (rng.standard_normal(100000) * 10.0 ** rng.uniform(-44, -30, 100000)).astype(np.float32)
+    tiny = np.float32(2.0 ** -126)
+    parts = [np.where(np.abs(p) < tiny, np.float32(0), p) for p in split3(x)]
+    back = parts[0].astype(np.float64) + parts[1] + parts[2]
+    assert np.all(np.abs(back - x.astype(np.float64)) < 3 * 2.0 ** -126)

@@ -3,7 +3,7 @@
 # command and separate FETCH_SIZE / WRITE_SIZE PMC passes (resident-batch segment only).
 TAG=$1
 R=$GRAFT_REPO_ROOT
-ONLY="--rotate-batches 0 --no-fg-capped --no-device-targets --no-direct-head-forward --no-fp32-mfma --pipeline-examples 0"
+ONLY="--rotate-batches 0 --no-fg-capped --no-device-targets --no-direct-head-forward --no-fp32-mfma --pipeline-examples 0 --no-extra-workloads"
 python $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
 python $R/bench.py --profile-all --no-cpu-baseline $ONLY > $R/gpurun_out/${TAG}_bench_allkinds.json 2>> $R/gpurun_out/${TAG}_bench.err
 python $R/bench.py --workload infer --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_bench_infer.json 2>> $R/gpurun_out/${TAG}_bench.err
