@@ -638,8 +638,9 @@ def main():
             v[k] = v[k] / R
     bucket_times = None
     if sync is not None:
-        bucket_times = [(ms / R, by / R, n) for ms, by, n in
-                        sync.exchange.bucket_times(len(sync.buckets.bounds))]
+        bucket_times = sync.exchange.bucket_times(len(sync.buckets.bounds))     # (None: exchange without timers)
+        if bucket_times is not None:
+            bucket_times = [(ms / R, by / R, n) for ms, by, n in bucket_times]
         sync.exchange.timing(False)
     n_rois = chain.last_targets['n_rois']
     loss_val = float(loss.item())

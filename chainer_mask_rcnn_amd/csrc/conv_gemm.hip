@@ -192,11 +192,6 @@ struct GemmParams {
     // (b / 256) x stagger_cycles shader cycles before its first load, so the phases interleave.
     // Placement only decides how well this works, never the result.
     int stagger_slots, stagger_cycles;
-    // N panels (FWD / DGRAD whole tiles): tiles are walked panel by panel — all M tiles of the first
-    // n_panel N-tiles, then of the next n_panel, ... — instead of N fastest over the whole width, so
-    // that the filter panel an XCD's resident workgroups sweep (n_panel x BN x K x 4 bytes) stays in
-    // its 4 MB L2 from one round of workgroups to the next (0: N fastest over the whole width).
-    int n_panel;
 };
 
 #ifdef MRCNN_GEMM_TRACE
@@ -459,17 +454,11 @@ conv_gemm_kernel(const GemmParams p)
         split = tile / (int)gridDim.x;
         tile -= split * (int)gridDim.x;
     }
-    int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
-    if (MODE != WGRAD && !tail && p.n_panel > 0 && p.n_panel < ntn) {
-        const int ntm = (p.tail_splits > 0 ? p.tail_first : (int)gridDim.x) / ntn;
-        const int per_panel = ntm * p.n_panel;          // (every panel but the last is full)
-        const int panel = tile / per_panel, r = tile - panel * per_panel;
-        const int w = min(p.n_panel, ntn - panel * p.n_panel);
-        tile_m = r / w;
-        tile_n = panel * p.n_panel + (r - tile_m * w);
-    }
-    const int m0 = p.m_lo + tile_m * BM;
-    const int n0 = tile_n * BN;
+    // (Walking the tiles N-panel by N-panel so that an XCD's resident workgroups sweep a filter panel
+    // that fits its L2 was measured in round 5 on res5's shapes, panels of 1 .. 8 N-tiles: every
+    // layer within +-2 % of the plain N-fastest walk, profiles/r05c_npanel.txt; removed.)
+    const int m0 = p.m_lo + (tile / ntn) * BM;
+    const int n0 = (tile % ntn) * BN;
 
     // ---------------- per-thread gather state -----------------------------------
     constexpr int KC_C4 = BK / 4, KC_RPP = 256 / KC_C4;   // float4 per row, rows per pass
@@ -1536,9 +1525,8 @@ int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM 
 int g_split_bf16 = 3;  // mrcnn_set_tuning("split_bf16"): bit 0 = 128x128 kernels, bit 1 = 64x64 forward form on the
                        // split-operand arithmetic (see SPLIT; the default since round 4), 0 = fp32 MFMA everywhere
 int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal start-up stagger; 0 = off)
-int g_n_panel = 0;    // mrcnn_set_tuning("n_panel"): GemmParams::n_panel for the 128x128 forward-form launches;
-                      // 0 = off, -1 = by filter size (panels of <= g_n_panel_kb KB), k > 0 = k N-tiles
-int g_n_panel_kb = 2048;
+int g_big_split_k = 0; // mrcnn_set_tuning("big_split_k"): target workgroup count for small-M problems run as
+                      // 128x128 tiles cut along K (0 = off: such problems run as 64x64 tiles)
 int g_stagger_min_rounds = 2;
 
 template <int TM, int TN, int MODE, bool MASKED>
@@ -1686,8 +1674,8 @@ bool can_split_rows(const GemmParams &p)
            p.ldc == p.N;
 }
 
-// rows [rows_lo, p.M) as 64x64 tiles cut along K into `splits` slabs + the ordered slab sum
-template <int MODE>
+// rows [rows_lo, p.M) as 64 TM x 64 TM tiles cut along K into `splits` slabs + the ordered slab sum
+template <int MODE, int TM = 1>
 void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_slices, hipStream_t s)
 {
     const int rows_left = p.M - rows_lo;
@@ -1700,7 +1688,7 @@ void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_s
     q.split_stride = (int64_t)rows_left * p.N;
     q.out_row0 = rows_lo;
     q.c_bytes = (unsigned)(q.split_stride * 4);
-    launch_tiles<1, 1, MODE>(q, rows_lo, p.M, splits, s);
+    launch_tiles<TM, TM, MODE>(q, rows_lo, p.M, splits, s);
     FixParams f = {};
     f.ws = p.split_ws; f.C = p.C;
     f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.residual = p.residual;
@@ -1839,7 +1827,15 @@ int launch(const GemmParams &p0, int splits, hipStream_t s)
     const int64_t tm = mrcnn::ceil_div(p.M, 128), tn = mrcnn::ceil_div(p.N, 128);
     const int64_t T = tm * tn;
     const bool big_ok = p.N > 64 && p.M > 64;
-    if (!big_ok || T < g_big_min_tiles) {
+    const int total_slices_ = p.R * p.S * (int)mrcnn::ceil_div(p.Kc, BK);
+    int64_t ksplits = 1;
+    if (g_big_split_k > 0 && big_ok && T < g_big_min_tiles && splits == 1 && can_split_rows<MODE>(p)) {
+        ksplits = std::min<int64_t>(std::min<int64_t>(8, total_slices_ / 8), mrcnn::ceil_div(g_big_split_k, T));
+        while (ksplits > 1 && (int64_t)p.M * p.N * ksplits * 4 > kSplitWsBytes) --ksplits;
+    }
+    if (ksplits >= 2) {
+        launch_split_rows<MODE, 2>(p, 0, (int)ksplits, total_slices_, s);
+    } else if (!big_ok || T < g_big_min_tiles) {
         launch_small<MODE>(p, s);
     } else {
         // whole "rounds" of k workgroups per CU (k = 3, 2, 1): pick the round size that leaves
@@ -1856,13 +1852,6 @@ int launch(const GemmParams &p0, int splits, hipStream_t s)
             }
         }
         const int rows_main = (int)std::min<int64_t>(p.M, main_tiles_m * 128);
-        if (g_n_panel > 0) {
-            p.n_panel = g_n_panel;
-        } else if (g_n_panel < 0) {
-            const int64_t tile_col_bytes = 128ll * p.R * p.S * p.Kc * 4;      // one N-tile of the filter
-            if (tn * tile_col_bytes > (int64_t)g_n_panel_kb * 1024 * 5 / 4)
-                p.n_panel = (int)std::max<int64_t>(1, (int64_t)g_n_panel_kb * 1024 / tile_col_bytes);
-        }
         if (!(splits == 1 && launch_fused_tail<2, 2, MODE>(p, rows_main, s))) {
             launch_tiles<2, 2, MODE>(p, 0, rows_main, splits, s);
             if (rows_main < p.M) launch_remainder<MODE>(p, rows_main, s);
@@ -2003,12 +1992,8 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
         g_stagger = value;
         return 0;
     }
-    if (strcmp(name, "n_panel") == 0) {
-        g_n_panel = value;
-        return 0;
-    }
-    if (strcmp(name, "n_panel_kb") == 0) {
-        g_n_panel_kb = value;
+    if (strcmp(name, "big_split_k") == 0) {
+        g_big_split_k = value;
         return 0;
     }
     if (strcmp(name, "stagger_min_rounds") == 0) {
