@@ -1525,8 +1525,8 @@ int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM 
 int g_split_bf16 = 3;  // mrcnn_set_tuning("split_bf16"): bit 0 = 128x128 kernels, bit 1 = 64x64 forward form on the
                        // split-operand arithmetic (see SPLIT; the default since round 4), 0 = fp32 MFMA everywhere
 int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal start-up stagger; 0 = off)
-int g_big_split_k = 0; // mrcnn_set_tuning("big_split_k"): target workgroup count for small-M problems run as
-                      // 128x128 tiles cut along K (0 = off: such problems run as 64x64 tiles)
+int g_big_split_k = 0;  // mrcnn_set_tuning("big_split_k"): small-M problems as 128x128 tiles cut along K.
+                      // 0 (default) = off (64x64 tiles), -1 = the rule in launch(), k > 0 = aim at k workgroups
 int g_stagger_min_rounds = 2;
 
 template <int TM, int TN, int MODE, bool MASKED>
@@ -1827,10 +1827,24 @@ int launch(const GemmParams &p0, int splits, hipStream_t s)
     const int64_t tm = mrcnn::ceil_div(p.M, 128), tn = mrcnn::ceil_div(p.N, 128);
     const int64_t T = tm * tn;
     const bool big_ok = p.N > 64 && p.M > 64;
+    // Small-M, K-deep problems (the batch-2 backbone's 3x3 layers on res4: M = 8568, N = 256,
+    // 72 K slices): 64x64 tiles load twice the operand bytes per MFMA of 128x128 tiles and reach
+    // ~100 TFLOP/s whatever their occupancy (profiles/r05f_small_m.txt: K splits of the 64x64 tiles are
+    // flat), while the 134 tiles of 128x128 fill half the CUs once.  When a K split puts those tiles
+    // into ONE round of the 512 resident workgroups at >= 75 % fill with >= 16 slices each, the
+    // 128x128 kernel plus the ordered slab sum is faster in isolation (98 -> 83 us forward, 97 -> 80 us
+    // data gradient, profiles/r05d_big_split_k.txt); other counts land in a nearly empty second round
+    // and lose.  In the train step the rule is worth 0.05 - 0.1 ms of 26 (same-box A/B,
+    // profiles/r05_ab_big_split_k.txt): opt-in ("big_split_k" = -1), not the default.
     const int total_slices_ = p.R * p.S * (int)mrcnn::ceil_div(p.Kc, BK);
     int64_t ksplits = 1;
-    if (g_big_split_k > 0 && big_ok && T < g_big_min_tiles && splits == 1 && can_split_rows<MODE>(p)) {
-        ksplits = std::min<int64_t>(std::min<int64_t>(8, total_slices_ / 8), mrcnn::ceil_div(g_big_split_k, T));
+    if (g_big_split_k != 0 && big_ok && T < g_big_min_tiles && splits == 1 && can_split_rows<MODE>(p)) {
+        if (g_big_split_k > 0) {
+            ksplits = std::min<int64_t>(std::min<int64_t>(8, total_slices_ / 8), mrcnn::ceil_div(g_big_split_k, T));
+        } else {
+            const int64_t fit = kSlotsBig / T;                 // splits that still make one round
+            if (fit >= 2 && fit <= 8 && T * fit >= kSlotsBig * 3 / 4 && total_slices_ / fit >= 16) ksplits = fit;
+        }
         while (ksplits > 1 && (int64_t)p.M * p.N * ksplits * 4 > kSplitWsBytes) --ksplits;
     }
     if (ksplits >= 2) {

@@ -215,7 +215,11 @@ int64_t mrcnn_conv2d_split_workspace_bytes(void);
  *   fp32 accumulation.  Error against float64 is at (measured: below) the fp32-MFMA kernels' level
  *   (tests/test_gpu_split_bf16.py, tests/test_split_arithmetic_cpu.py).
  *   "big_min_tiles" (default 384): fewest 128x128 tiles for which the 128x128 kernels are used
- *   (1 forces them; lets small test problems exercise the kernels of the full-size step). */
+ *   (1 forces them; lets small test problems exercise the kernels of the full-size step).
+ *   "big_split_k" (default 0 = off): with -1, a small-M, K-deep forward-form problem whose 128x128
+ *   tiles cut along K fill one round of the resident workgroups (the batch-2 res4 3x3 layers) runs
+ *   that way, slabs summed in order by the epilogue kernel, instead of as 64x64 tiles; k > 0 = aim
+ *   at k workgroups (probe).  Summation order differs between the settings (each deterministic). */
 int mrcnn_set_tuning(const char *name, int value);
 int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                      const float *bias, const float *scale, const float *shift,

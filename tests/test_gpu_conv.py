@@ -433,7 +433,21 @@ def test_fused_stage_matches_bottleneck_chain(dev, shape, chans, stride):
     (2, 128, 101, 167, 128, 3),    # res3 3x3: 1056 tiles
     (1, 64, 67, 131, 64, 1),       # only 2 K slices: no split (too shallow)
 ])
-def test_small_m_split_k_leftover_rows(dev, case):
+@pytest.mark.parametrize('big_split_k', [0, -1, 512],
+                         ids=['64x64 tiles (shipped)', 'one-round rule', '128x128 tiles cut along K'])
+def test_small_m_split_k_leftover_rows(dev, case, big_split_k):
+    """The small-M tile policies of csrc/conv_gemm.hip launch(): 64x64 tiles with K-split leftover
+    rows (shipped), and 128x128 tiles cut along K over all rows (opt-in: the one-round rule picks them
+    for the res4 3x3 shape) — forward with the whole fused epilogue and every gradient vs float64."""
+    from chainer_mask_rcnn_amd import _lib
+    _lib.set_tuning('big_split_k', big_split_k)
+    try:
+        _small_m_case(dev, case)
+    finally:
+        _lib.set_tuning('big_split_k', 0)
+
+
+def _small_m_case(dev, case):
     N, C, H, W, K, k = case
     rng = np.random.RandomState(sum(case))
     x = rng.standard_normal((N, C, H, W)).astype(np.float32)
