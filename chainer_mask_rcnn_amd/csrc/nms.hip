@@ -12,12 +12,13 @@
 //      j says IoU(row_i, col_j) >= thresh.  A wave is exactly one mask word wide.
 //      For the diagonal tiles lane j also emits its COLUMN word (bit i: box i < j suppresses
 //      box j) — IoU is symmetric bit for bit, so it is the lower triangle of the same tile.
-//   2. nms_scan_kernel  — one workgroup per NMS problem walks the 64-row chunks:
-//      the in-chunk dependency is resolved by a fixpoint iteration on the column words
-//      (K <- candidates not suppressed by an earlier member of K; one ballot + AND per
+//   2. nms_scan_kernel  — one workgroup per NMS problem walks the 64-row chunks, eight to a
+//      super-step: the in-chunk dependency is resolved by a fixpoint iteration on the column
+//      words (K <- candidates not suppressed by an earlier member of K; one ballot + AND per
 //      iteration, exact: the greedy keep set is its unique fixpoint and iteration t fixes
-//      at least the first t candidates), then all threads OR the kept rows into the
-//      `removed` bit-vector held in LDS (coalesced row reads, all issued together).
+//      at least the first t candidates), the dependency between the chunks of a super-step from
+//      pre-loaded words in registers, and once per super-step all threads OR the kept rows into
+//      the `removed` bit-vector held in LDS (one global round trip).
 //
 // IoU uses the CPU path's exact fp32 operation sequence (no FMA:
 // -ffp-contract=off), so keep sets are bit-identical to oracle/nms_ref.c.
@@ -93,107 +94,127 @@ __device__ __forceinline__ uint64_t readfirstlane64(uint64_t v)
 }
 
 // grid (groups), block 64 * W (W = 4 or 16 waves), dynamic LDS = nblk_max * 8 bytes.
-// Per 64-row chunk: wave 0 resolves the in-chunk dependency from the 64 diagonal words (the
-// next chunk's diagonal is already in flight), then every wave ORs "its" kept rows (row j
-// belongs to wave j mod W, so at most 64 / W row loads per lane, all issued back to back)
-// into the removed bit-vector with LDS atomics.  The chain per chunk is one global round
-// trip, not one per kept row.
+// The keep decision of a 64-row chunk depends on every earlier chunk, so the chunks are a serial
+// chain; what the chain costs per link is the design.  Round 4 paid one global round trip and two
+// workgroup barriers PER CHUNK (188 chunks for the RPN's 12 000 boxes: 0.46 ms).  Here S = 8 chunks
+// form a super-step:
+//   * wave 0 walks the S chunks alone, without a barrier and without touching global memory on
+//     the way: the words that couple the chunks of one super-step — row r's mask word for the
+//     LATER chunks of the same super-step, 28 per lane — do not depend on any decision, so they were
+//     loaded during the previous super-step's bulk phase (as were the S diagonal column words).  Per
+//     chunk: removed-word from LDS, the fixpoint iteration on the column words (exact: the greedy
+//     keep set is its unique fixpoint, iteration t fixes at least the first t candidates), keep-list
+//     and kept-row-list writes, and the kept lanes OR their in-super-step words into LDS;
+//   * one bulk phase per super-step: all waves OR the kept rows of its S chunks into the removed
+//     bit-vector for every later column — (kept row, column) pairs dealt out evenly over the
+//     threads, eight independent loads in flight per thread, one global round trip.
+// Chain cost: 24 super-steps x (8 chunk links in registers / LDS + 1 round trip + 2 barriers).
+constexpr int kScanS = 8;
+
 __global__ void __launch_bounds__(1024)
 nms_scan_kernel(const uint64_t *__restrict__ mask_all, const uint64_t *__restrict__ diag_t_all,
                 const int32_t *__restrict__ n_dev, int n_max, int nblk_max, int limit,
                 int32_t *__restrict__ keep_all, int32_t *__restrict__ n_keep_all)
 {
+    constexpr int S = kScanS;
     extern __shared__ __attribute__((aligned(16))) uint64_t removed[];
-    __shared__ uint64_t s_kept;
-    __shared__ int s_count;
+    __shared__ int s_rows[S * 64];      // kept rows of the current super-step, in order
+    __shared__ int s_nk, s_count;
     const int g = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     const uint64_t *__restrict__ mask = mask_all + (int64_t)g * n_max * nblk_max;
     const uint64_t *__restrict__ diag_t = diag_t_all + (int64_t)g * n_max;
     int32_t *__restrict__ keep = keep_all + (int64_t)g * n_max;
     const int n = min(n_dev ? n_dev[g] : n_max, n_max);
     const int nblk = (n + 63) / 64;
-    for (int c = tid; c < nblk; c += blockDim.x) removed[c] = 0;
-    if (tid == 0) s_count = 0;
-    // rows this wave ORs in: bits j with j % nwaves == wave
-    uint64_t mine = 0;
-    for (int j = wave; j < 64; j += nwaves) mine |= 1ull << j;
-    uint64_t col = 0;       // wave 0: column word of row blk * 64 + lane
-    if (wave == 0 && lane < n) col = diag_t[lane];
+    for (int c = tid; c < nblk; c += nthr) removed[c] = 0;
+    if (tid == 0) { s_count = 0; s_nk = 0; }
+
+    // wave 0: per chunk c of the super-step, this lane's row: its diagonal column word and its
+    // mask words for the later chunks of the same super-step (dw[c][d]: column sblk + c + 1 + d)
+    uint64_t col[S], dw[S][S - 1];
+    auto prefetch = [&](int sblk) {
+#pragma unroll
+        for (int c = 0; c < S; ++c) {
+            const int row = (sblk + c) * 64 + lane;
+            const bool ok = row < n;
+            col[c] = ok ? diag_t[row] : 0ull;
+#pragma unroll
+            for (int d = 0; d < S - 1 - c; ++d)
+                dw[c][d] = (ok && sblk + c + 1 + d < nblk)
+                               ? mask[(int64_t)row * nblk_max + sblk + c + 1 + d] : 0ull;
+        }
+    };
+    if (wave == 0) prefetch(0);
     __syncthreads();
 
-    for (int blk = 0; blk < nblk; ++blk) {
+    int cnt = 0;                         // wave 0: boxes kept so far (wave-uniform)
+    for (int sblk = 0; sblk < nblk; sblk += S) {
         if (wave == 0) {
-            const int row = blk * 64 + lane;
-            uint64_t rem = readfirstlane64(removed[blk]);
-            const int nrow = n - blk * 64;
-            if (nrow < 64) rem |= ~((1ull << nrow) - 1ull);
-            // fixpoint: K <- candidates whose column word meets no member of K
-            const uint64_t cand = ~rem;
-            uint64_t kept = cand;
-            for (int it = 0; it < 64; ++it) {
-                const uint64_t sup = __ballot((col & kept) != 0ull);
-                const uint64_t next = cand & ~sup;
-                if (next == kept) break;
-                kept = next;
+            int nk = 0;
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+                const int blk = sblk + c;
+                if (blk < nblk && !(limit > 0 && cnt >= limit)) {          // (wave-uniform)
+                    const int row = blk * 64 + lane;
+                    uint64_t rem = readfirstlane64(*(volatile uint64_t *)&removed[blk]);
+                    const int nrow = n - blk * 64;
+                    if (nrow < 64) rem |= ~((1ull << nrow) - 1ull);
+                    // fixpoint: K <- candidates whose column word meets no member of K
+                    const uint64_t cand = ~rem;
+                    uint64_t kept = cand;
+                    for (int it = 0; it < 64; ++it) {
+                        const uint64_t sup = __ballot((col[c] & kept) != 0ull);
+                        const uint64_t next = cand & ~sup;
+                        if (next == kept) break;
+                        kept = next;
+                    }
+                    if (limit > 0) {
+                        const int room = limit - cnt;
+                        while (__popcll(kept) > room) kept &= ~(1ull << (63 - __clzll((long long)kept)));
+                    }
+                    const bool mine = (kept >> lane) & 1ull;
+                    const int rank = __popcll(kept & ((1ull << lane) - 1ull));
+                    if (mine) {
+                        keep[cnt + rank] = row;
+                        s_rows[nk + rank] = row;
+#pragma unroll
+                        for (int d = 0; d < S - 1 - c; ++d)
+                            if (dw[c][d])
+                                atomicOr(reinterpret_cast<unsigned long long *>(&removed[blk + 1 + d]),
+                                         (unsigned long long)dw[c][d]);
+                    }
+                    const int k = __popcll(kept);
+                    cnt += k;
+                    nk += k;
+                }
             }
-            // next chunk's column words: in flight across the barrier and the OR phase
-            const int nrow_next = row + 64;
-            col = (blk + 1 < nblk && nrow_next < n) ? diag_t[nrow_next] : 0ull;
-            const int cnt = s_count;
-            if (limit > 0) {
-                int room = limit - cnt;
-                while (__popcll(kept) > room) kept &= ~(1ull << (63 - __clzll((long long)kept)));
-            }
-            if ((kept >> lane) & 1ull)
-                keep[cnt + __popcll(kept & ((1ull << lane) - 1ull))] = row;
-            if (lane == 0) {
-                s_kept = kept;
-                s_count = cnt + __popcll(kept);
-            }
+            if (lane == 0) { s_nk = nk; s_count = cnt; }
+            // the next super-step's words: in flight across the barrier and the bulk phase
+            if (sblk + S < nblk) prefetch(sblk + S);
         }
         __syncthreads();
-        const uint64_t kept = s_kept;
-        const int cnt = s_count;
-        if (limit > 0 && cnt >= limit) break;
-        const uint64_t k_mine = kept & mine;
-        if (k_mine) {
-            // Every load of this phase is issued before any result is used (addresses are
-            // clamped instead of predicated, so there is no branch between the loads): up to
-            // four kept rows x four column words per lane are in flight together and a chunk
-            // costs ONE memory latency.
-            const uint64_t *__restrict__ rows = mask + (int64_t)blk * 64 * nblk_max;
-            for (int cbase = blk + 1 + lane; cbase < nblk; cbase += 256) {
-                uint64_t acc[4] = {0ull, 0ull, 0ull, 0ull};
-                uint64_t k = k_mine;
-                while (k) {
-                    int j[4];
-                    uint64_t sel[4];
+        if (limit > 0 && s_count >= limit) break;
+        // bulk phase: (kept row q, column) pairs over the columns behind this super-step
+        const int col0 = sblk + S, ncols = nblk - col0, nk = s_nk;
+        if (ncols > 0 && nk > 0) {
+            const int npairs = nk * ncols;
+            for (int p0 = 0; p0 < npairs; p0 += 8 * nthr) {
+                uint64_t w[8];
+                int cw[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sel[r] = k ? ~0ull : 0ull;
-                        j[r] = k ? __ffsll((long long)k) - 1 : 0;
-                        k &= k - 1;
-                    }
-                    uint64_t m[4][4];
-#pragma unroll
-                    for (int ci = 0; ci < 4; ++ci) {
-                        const int c = min(cbase + 64 * ci, nblk - 1);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) m[ci][r] = rows[(int64_t)j[r] * nblk_max + c];
-                    }
-#pragma unroll
-                    for (int ci = 0; ci < 4; ++ci) {
-                        const uint64_t ok = cbase + 64 * ci < nblk ? ~0ull : 0ull;
-                        acc[ci] |= ok & ((m[ci][0] & sel[0]) | (m[ci][1] & sel[1]) |
-                                         (m[ci][2] & sel[2]) | (m[ci][3] & sel[3]));
-                    }
+                for (int u = 0; u < 8; ++u) {
+                    const int p = p0 + u * nthr + tid;
+                    const int pc = p < npairs ? p : 0;              // clamped: no branch between the loads
+                    const int q = pc / ncols, ci = pc - q * ncols;
+                    cw[u] = p < npairs ? col0 + ci : -1;
+                    w[u] = mask[(int64_t)s_rows[q] * nblk_max + col0 + ci];
                 }
 #pragma unroll
-                for (int ci = 0; ci < 4; ++ci)
-                    if (acc[ci])
-                        atomicOr(reinterpret_cast<unsigned long long *>(&removed[cbase + 64 * ci]),
-                                 (unsigned long long)acc[ci]);
+                for (int u = 0; u < 8; ++u)
+                    if (cw[u] >= 0 && w[u])
+                        atomicOr(reinterpret_cast<unsigned long long *>(&removed[cw[u]]),
+                                 (unsigned long long)w[u]);
             }
         }
         __syncthreads();
