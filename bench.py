@@ -526,7 +526,17 @@ def main():
                     help='developer: comma-separated mrcnn_set_tuning knobs, e.g. small_m_split=4')
     ap.add_argument('--bucket-mb', type=float, default=16.0,
                     help='gradient all-reduce bucket size (data-parallel runs)')
+    ap.add_argument('--all-legs', action='store_true',
+                    help='multi-GPU runs: also run the auxiliary single-GPU measurements (rotating_h2d, '
+                         'fg_capped, device_targets, direct_head_forward, fp32_mfma, pipeline_h2d); by default '
+                         'a run with --gpus > 1 times the headline region only')
     args = ap.parse_args()
+    if args.gpus > 1 and not args.all_legs:
+        # the scaling runs need `value` per N; every auxiliary leg is one more place where eight
+        # ranks must stay in step, and none of them says anything about scaling
+        args.rotate_batches = 0
+        args.pipeline_examples = 0
+        args.fg_capped = args.device_targets = args.direct_head_forward = args.fp32_mfma = False
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_launch(args)
