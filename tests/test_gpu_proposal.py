@@ -41,6 +41,30 @@ def test_nms_limit_and_dense_overlap(dev):
         assert np.array_equal(k, ref)
 
 
+@pytest.mark.parametrize('n', [511, 512, 513, 575, 1024, 1025, 4097, 12000])
+def test_nms_super_step_structure(dev, n):
+    """csrc/nms.hip walks the 64-box chunks eight to a super-step (the coupling between the chunks
+    of a super-step comes from pre-loaded words, the rest from one bulk phase per super-step):
+    box counts around the super-step size, a staircase of boxes in which every box overlaps its
+    successors across chunk AND super-step boundaries (long dependency chains), and limits that
+    are reached in every position of a super-step."""
+    rng = np.random.RandomState(n)
+    # staircase: box i = [i * d, i * d + 40] squares; IoU with box i + k falls with k
+    d = rng.uniform(1.0, 9.0)
+    off = np.arange(n, dtype=np.float64) * d % 700.0
+    stair = np.stack([off, off, off + 40.0, off + 40.0], 1).astype(np.float32)
+    mixed = np.where((rng.rand(n, 1) < 0.5), stair, _rand_boxes(rng, n)).astype(np.float32)
+    for bbox, thresh in ((stair, 0.5), (mixed, 0.7)):
+        full = oracle.nms_sorted(bbox, thresh)
+        limits = [0] + sorted(set(int(x) for x in (1, len(full) // 3, len(full) // 2 + 1, len(full) - 1, len(full),
+                                                   len(full) + 5) if x > 0))
+        for limit in limits:
+            keep, n_keep = P.nms_sorted(torch.tensor(bbox, device=dev), thresh, limit=limit)
+            k = keep[:int(n_keep.item())].cpu().numpy()
+            ref = oracle.nms_sorted(bbox, thresh, limit if limit > 0 else -1)
+            assert np.array_equal(k, ref), (n, thresh, limit, len(k), len(ref))
+
+
 def test_nms_degenerate(dev):
     bbox = np.array([[5, 5, 5, 5], [5, 5, 5, 5], [0, 0, 10, 10], [0, 0, 10, 10]], np.float32)
     keep, n_keep = P.nms_sorted(torch.tensor(bbox, device=dev), 0.5)
