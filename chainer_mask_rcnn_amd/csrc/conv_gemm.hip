@@ -192,7 +192,6 @@ struct GemmParams {
     // (b / 256) x stagger_cycles shader cycles before its first load, so the phases interleave.
     // Placement only decides how well this works, never the result.
     int stagger_slots, stagger_cycles;
-    int pipe;            // host only: launch the software-pipelined instantiation (PIPE) where it exists
 };
 
 #ifdef MRCNN_GEMM_TRACE
@@ -363,39 +362,11 @@ __device__ __forceinline__ void sgb_interleave()
     }
 }
 
-// Issue order of one K slice of the PIPE kernel (below): 48 MFMAs with, between them, the staging of
-// the NEXT slice (about four vector-ALU instructions and half an LDS store per MFMA), the second K
-// step's fragment reads and the loads of the slice after next — a single wave keeps its SIMD's
-// matrix pipe busy without a second wave to take turns with (MI355X_MICROARCH.md: about five
-// single-issue instructions are hidden per 32-cycle MFMA).
-template <int NM, int I = 0>
-__device__ __forceinline__ void sgb_pipe()
-{
-    if constexpr (I < NM) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        if constexpr (I >= 3 && I % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        if constexpr (I >= 2 && I < 14) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if constexpr (I % 6 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        sgb_pipe<NM, I + 1>();
-    }
-}
-
-// PIPE (SPLIT forward form 128x128, unmasked): the software-pipelined instantiation for problems
-// that give a CU ONE workgroup (the batch-2 backbone: 134 .. 536 tiles for 256 CUs).  The standard
-// instantiations hide a wave's staging (load wait, split, LDS stores: ~4 500 of its ~6 000 cycles
-// per slice) behind the MFMAs of two or three co-resident workgroups; with one workgroup per CU
-// nothing hides it.  Here a wave does it itself: two LDS stages, one barrier per slice, and inside
-// the slice's MFMA stream (a) the split + LDS stores of slice k + 1 from registers loaded one
-// iteration earlier and (b) the loads of slice k + 2 into a second register set (one wave per SIMD:
-// the 512-entry register file is its own).
-template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false, bool PIPE = false>
-__global__ void __launch_bounds__(256, SPLIT ? (PIPE ? 1 : (TM == 2 ? 2 : 4)) : min_blocks(TM, MODE, MASKED))
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false>
+__global__ void __launch_bounds__(256, SPLIT ? (TM == 2 ? 2 : 4) : min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
-    static_assert(!PIPE || (SPLIT && MODE == FWD && !MASKED && TM == 2 && TN == 2 && MRCNN_SPLIT_ILV != 0),
-                  "PIPE: the unmasked 128x128 split-operand forward form");
     constexpr bool ILV = MRCNN_SPLIT_ILV != 0 && SPLIT && MODE == FWD && !MASKED;
     static_assert(!SPLIT || (BK == 32 && TM == TN &&
                              ((MODE == FWD && (TM == 1 || TM == 2)) || (MODE == WGRAD && !WPERM && TM == 2))),
@@ -414,7 +385,7 @@ conv_gemm_kernel(const GemmParams p)
     constexpr int SROW = MODE == WGRAD ? BK + 8 : BK;     // ushorts per plane row
     constexpr int PLA = BM * SROW, PLB = BN * SROW;       // ushorts per plane
     constexpr int STAGE_FLOATS = SPLIT ? 3 * (PLA + PLB) / 2 : C_::A_FLOATS + C_::B_FLOATS;
-    __shared__ __attribute__((aligned(16))) float smem_all[1][SINGLEBUF && !PIPE ? 1 : 2][STAGE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem_all[1][SINGLEBUF ? 1 : 2][STAGE_FLOATS];
 
     float (*smem)[STAGE_FLOATS] = smem_all[0];
     // SPLIT WGRAD (80-byte rows, no swizzle): plane row 32 c + l holds channel 4 l + c of the tile
@@ -632,7 +603,6 @@ conv_gemm_kernel(const GemmParams p)
     }
 
     float4 ra[AV], rb[BV];
-    float4 ra2[PIPE ? AV : 1], rb2[PIPE ? BV : 1];       // PIPE: the second register set in flight
     float4 rm[HAS_MASK ? AV : 1];
     float4 rscale = make_float4(1.f, 1.f, 1.f, 1.f);
     const bool use_scale = HAS_MASK && p.in_scale != nullptr;
@@ -1069,90 +1039,6 @@ conv_gemm_kernel(const GemmParams p)
     if (tid == 0 && probe_slot < (unsigned)kProbeSlots) g_probe2[probe_slot * 8] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (MRCNN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(2);
-    if constexpr (PIPE) {
-        // one slice: MFMAs on stage `buf`; `cur` (slice kt + 1, loaded an iteration ago) is split and
-        // stored into the other stage; the loads of slice kt + 2 (offsets oa / ob) go into `nxt`
-        auto pipe_step = [&](int buf, float4 (&cur_a)[AV], float4 (&cur_b)[BV], float4 (&nxt_a)[AV],
-                             float4 (&nxt_b)[BV]) {
-            const unsigned short *pa = reinterpret_cast<const unsigned short *>(smem[buf]);
-            const unsigned short *pb = pa + 3 * PLA;
-            unsigned short *qa = reinterpret_cast<unsigned short *>(smem[buf ^ 1]);
-            unsigned short *qb = qa + 3 * PLA;
-            bf16x8 fa[2][TM][3], fb[2][TN][3];
-            auto frag = [&](int ks, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        a[i][q] = *reinterpret_cast<const bf16x8 *>(
-                            pa + q * PLA + (wm * (32 * TM) + i * 32 + li) * SROW +
-                            (((ks * 4 + lk * 2) ^ swz(wm * (32 * TM) + i * 32 + li)) << 2));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        b[j][q] = *reinterpret_cast<const bf16x8 *>(
-                            pb + q * PLB + (wn * (32 * TN) + j * 32 + li) * SROW +
-                            (((ks * 4 + lk * 2) ^ swz(wn * (32 * TN) + j * 32 + li)) << 2));
-            };
-            auto put = [&](unsigned short *plane0, int plane_len, int row, float4 v) {
-                unsigned h0, m0_, l0, h1, m1, l1;
-                split3(v.x, v.y, h0, m0_, l0);
-                split3(v.z, v.w, h1, m1, l1);
-                unsigned short *q = plane0 + row * SROW + ((kc_c4 ^ swz(row)) << 2);
-                *reinterpret_cast<uint2 *>(q) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2 *>(q + plane_len) = make_uint2(m0_, m1);
-                *reinterpret_cast<uint2 *>(q + 2 * plane_len) = make_uint2(l0, l1);
-            };
-            frag(0, fa[0], fb[0]);
-            frag(1, fa[1], fb[1]);
-#pragma unroll
-            for (int i = 0; i < AV; ++i) nxt_a[i] = bload4(rA, oa[i]);
-#pragma unroll
-            for (int i = 0; i < BV; ++i) nxt_b[i] = bload4(rB, ob[i]);
-#pragma unroll
-            for (int i = 0; i < AV; ++i) put(qa, PLA, kc_row + KC_RPP * i, cur_a[i]);
-#pragma unroll
-            for (int i = 0; i < BV; ++i) put(qb, PLB, kc_row + KC_RPP * i, cur_b[i]);
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                constexpr int QA[6] = {0, 2, 1, 1, 0, 0}, QB[6] = {2, 0, 1, 0, 1, 0};
-#pragma unroll
-                for (int c = 0; c < 6; ++c)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                fa[ks][i][QA[c]], fb[ks][j][QB[c]], acc[i][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);     // first K step's fragments
-            sgb_pipe<6 * TM * TN * (BK / 16)>();
-        };
-        auto no_loads = [&]() {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) oa[i] = kOOB;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) ob[i] = kOOB;
-        };
-        if (nslices > 0) {
-            load_slice(0);
-            issue_loads();                       // ra / rb <- slice 0
-            store_slice(0);
-            if (nslices > 1) load_slice(1); else no_loads();
-            issue_loads();                       // ra / rb <- slice 1 (in flight)
-        }
-        __syncthreads();
-        for (int kt = 0; kt < nslices; kt += 2) {
-            if (kt + 2 < nslices) load_slice(kt + 2); else no_loads();
-            pipe_step(0, ra, rb, ra2, rb2);      // slice kt; stage 1 <- slice kt + 1; ra2 / rb2 <- slice kt + 2
-            __syncthreads();
-            if (kt + 1 >= nslices) break;
-            if (kt + 3 < nslices) load_slice(kt + 3); else no_loads();
-            pipe_step(1, ra2, rb2, ra, rb);      // slice kt + 1; stage 0 <- slice kt + 2; ra / rb <- slice kt + 3
-            __syncthreads();
-        }
-    } else {
     if (nslices > 0) {
         load_slice(0);
         issue_loads();
@@ -1235,7 +1121,6 @@ conv_gemm_kernel(const GemmParams p)
         }
 #undef TRACE_STAMP
     }
-    }   // !PIPE
 
 #ifdef MRCNN_GEMM_CLOCKPROBE
     if (tid == 0 && probe_slot < (unsigned)kProbeSlots) g_probe2[probe_slot * 8 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1640,7 +1525,6 @@ int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM 
 int g_split_bf16 = 3;  // mrcnn_set_tuning("split_bf16"): bit 0 = 128x128 kernels, bit 1 = 64x64 forward form on the
                        // split-operand arithmetic (see SPLIT; the default since round 4), 0 = fp32 MFMA everywhere
 int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal start-up stagger; 0 = off)
-int g_pipe = 0;         // mrcnn_set_tuning("pipe"): 1 = every unmasked 128x128 forward-form launch on the PIPE kernel (probe)
 int g_big_split_k = 0;  // mrcnn_set_tuning("big_split_k"): small-M problems as 128x128 tiles cut along K.
                       // 0 (default) = off (64x64 tiles), -1 = the rule in launch(), k > 0 = aim at k workgroups
 int g_stagger_min_rounds = 2;
@@ -1683,14 +1567,6 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
     if constexpr (MODE == WGRAD && !MASKED) {
         if (p.perm_n > 0) {
             hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, true>),
-                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1, 0,
-                                  p);
-            return;
-        }
-    }
-    if constexpr (MODE == FWD && TM == 2 && TN == 2 && !MASKED) {
-        if ((g_split_bf16 & 1) && p.pipe) {
-            hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true, true>),
                                dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1, 0,
                                   p);
             return;
@@ -1948,7 +1824,6 @@ template <int MODE>
 int launch(const GemmParams &p0, int splits, hipStream_t s)
 {
     GemmParams p = p0;
-    p.pipe = g_pipe == 1;
     const int64_t tm = mrcnn::ceil_div(p.M, 128), tn = mrcnn::ceil_div(p.N, 128);
     const int64_t T = tm * tn;
     const bool big_ok = p.N > 64 && p.M > 64;
@@ -2129,10 +2004,6 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "stagger") == 0) {
         g_stagger = value;
-        return 0;
-    }
-    if (strcmp(name, "pipe") == 0) {
-        g_pipe = value;
         return 0;
     }
     if (strcmp(name, "big_split_k") == 0) {
