@@ -69,3 +69,45 @@ def test_stage_backward_matches_autograd():
     for k, g in G.items():
         np.testing.assert_allclose(g, T[k].grad.numpy(), rtol=1e-8, atol=1e-9, err_msg=k)
     assert set(G) == {k for k in P if '.conv' in k}
+
+
+def test_relu_decisions_can_be_recorded_and_forced():
+    """np_step.RELU_PRE / RELU_FORCE (the decision-conditioned form of tests/test_gpu_step_golden.py):
+    forcing the step's OWN decisions reproduces it bit for bit; flipping one unit with a non-zero
+    gradient changes the gradients below it and nothing above; recording never changes a result."""
+    cfg = dict(n_layers=50, H=96, W=128, batch=1, n_gt=2, n_sample=8,
+               proposal_creator_params=dict(min_size=0, n_train_pre_nms=200, n_train_post_nms=40))
+    P = np_step.synthetic_params(cfg['n_layers'], seed=0)
+    inputs = np_step.synthetic_inputs(5, cfg['batch'], cfg['H'], cfg['W'], n_gt=cfg['n_gt'], scale=1.0)
+
+    def run(force=None, record=None):
+        np.random.seed(3)
+        np_step.RELU_FORCE, np_step.RELU_PRE = force, record
+        try:
+            return np_step.train_step(P, *inputs, n_layers=cfg['n_layers'], n_sample=cfg['n_sample'],
+                                      proposal_creator_params=cfg['proposal_creator_params'])
+        finally:
+            np_step.RELU_FORCE = np_step.RELU_PRE = None
+
+    free = run()
+    pre = {}
+    rec = run(record=pre)
+    sites = sorted(pre)
+    assert 'rpn.conv1' in sites and 'head.deconv6' in sites and 'extractor.res3.a.1' in sites
+    assert not any(s.startswith('extractor.res2') for s in sites)          # below freeze_at: no backward
+    own = {s: p > 0 for s, p in pre.items()}
+    same = run(force=own)
+    for out in (rec, same):
+        assert out['losses'] == free['losses']
+        for k, g in free['grads'].items():
+            assert np.array_equal(out['grads'][k], g), k
+    # flip the decision of the res4 unit with the largest pre-activation
+    site = 'extractor.res4.b3.2'
+    flipped = dict(own)
+    m = own[site].copy()
+    idx = np.unravel_index(np.argmax(pre[site]), m.shape)
+    m[idx] = False
+    flipped[site] = m
+    out = run(force=flipped)
+    assert not np.array_equal(out['grads']['extractor.res4.b3.conv2.W'], free['grads']['extractor.res4.b3.conv2.W'])
+    assert not np.array_equal(out['grads']['extractor.res3.a.conv1.W'], free['grads']['extractor.res3.a.conv1.W'])
