@@ -192,8 +192,6 @@ struct GemmParams {
     // (b / 256) x stagger_cycles shader cycles before its first load, so the phases interleave.
     // Placement only decides how well this works, never the result.
     int stagger_slots, stagger_cycles;
-    // stream-K launches (SK instantiation): tiles, K slices per tile, units per workgroup
-    int sk_tiles, sk_slices, sk_len;
 };
 
 #ifdef MRCNN_GEMM_TRACE
@@ -364,22 +362,11 @@ __device__ __forceinline__ void sgb_interleave()
     }
 }
 
-// SK ("stream-K", SPLIT forward form 128x128, unmasked): the launch is a fixed number of workgroups —
-// one round of the resident slots — and each walks a CONTIGUOUS RANGE of (tile, K slice) units, tile
-// major: sk_len units from unit workgroup * sk_len on.  A range that ends inside a tile, starts inside
-// one or covers one whole is a segment; every segment stores its raw partial sums into slab number
-// (workgroup - first workgroup that touches the tile) of the split-K workspace, and the ordered slab
-// sum (splitk_epilogue_kernel, which derives each tile's slab count from the same arithmetic) applies
-// the epilogue.  For problems too small to fill the CUs with whole 128x128 tiles (the batch-2
-// backbone) this removes the round quantisation that defeats a uniform K split: every workgroup
-// gets the same number of slices whatever the tile count.
-template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false, bool SK = false>
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false>
 __global__ void __launch_bounds__(256, SPLIT ? (TM == 2 ? 2 : 4) : min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
-    static_assert(!SK || (SPLIT && MODE == FWD && !MASKED && TM == 2 && TN == 2),
-                  "SK: the unmasked 128x128 split-operand forward form");
     constexpr bool ILV = MRCNN_SPLIT_ILV != 0 && SPLIT && MODE == FWD && !MASKED;
     static_assert(!SPLIT || (BK == 32 && TM == TN &&
                              ((MODE == FWD && (TM == 1 || TM == 2)) || (MODE == WGRAD && !WPERM && TM == 2))),
@@ -451,32 +438,22 @@ conv_gemm_kernel(const GemmParams p)
     // the slow index, so the tiles of one split — which all stream the same pixel range of gy
     // and x — land on one or two XCDs instead of all eight.
     const int ntn = (p.N + BN - 1) / BN;
-    int tile0 = blockIdx.x + blockIdx.y * gridDim.x;
-    int split0 = 0;
-    int split_len0 = p.split_len;
-    const bool tail0 = !SK && MODE != WGRAD && p.tail_splits > 0 && tile0 >= p.tail_first;   // uniform
-    if (SK) {
-        // (the segments are chosen below; the XCD remap applies to the workgroup index: consecutive
-        // ranges — neighbouring tiles — run on one XCD)
-        const int nwg = (int)gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = tile0 & 7, idx = tile0 >> 3;
-        tile0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    } else if (tail0) {
-        const int rem = tile0 - p.tail_first;
-        split0 = rem % p.tail_splits;
-        tile0 = p.tail_first + rem / p.tail_splits;
-        split_len0 = p.tail_split_len;
+    int tile = blockIdx.x + blockIdx.y * gridDim.x;
+    int split;
+    int split_len = p.split_len;
+    const bool tail = MODE != WGRAD && p.tail_splits > 0 && tile >= p.tail_first;   // uniform
+    if (tail) {
+        const int rem = tile - p.tail_first;
+        split = rem % p.tail_splits;
+        tile = p.tail_first + rem / p.tail_splits;
+        split_len = p.tail_split_len;
     } else {
         const int nwg = (MODE != WGRAD && p.tail_splits > 0) ? p.tail_first : (int)(gridDim.x * gridDim.y);
-        const int q = nwg >> 3, r = nwg & 7, xcd = tile0 & 7, idx = tile0 >> 3;
-        tile0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        split0 = tile0 / (int)gridDim.x;
-        tile0 -= split0 * (int)gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        split = tile / (int)gridDim.x;
+        tile -= split * (int)gridDim.x;
     }
-    // One tile (or one K range of a tile): everything from the gather set-up to the epilogue.
-    // kt0_in >= 0 (SK): the first K slice of the range; -1: split * split_len.
-    auto run_tile = [&](const int tile, const int split, const int split_len, const int kt0_in,
-                        const bool tail) {
     // (Walking the tiles N-panel by N-panel so that an XCD's resident workgroups sweep a filter panel
     // that fits its L2 was measured in round 5 on res5's shapes, panels of 1 .. 8 N-tiles: every
     // layer within +-2 % of the plain N-fastest walk, profiles/r05c_npanel.txt; removed.)
@@ -611,7 +588,7 @@ conv_gemm_kernel(const GemmParams p)
     int kt0 = 0;
     int nslices = (MODE == WGRAD) ? (k_end - k_begin + BK - 1) / BK : ntaps * cprs;
     if (MODE != WGRAD && split_len > 0) {
-        kt0 = kt0_in >= 0 ? kt0_in : split * split_len;
+        kt0 = split * split_len;
         nslices = max(0, min(nslices - kt0, split_len));
     }
 
@@ -1510,25 +1487,6 @@ conv_gemm_kernel(const GemmParams p)
         }
     }
 #endif
-    };   // run_tile
-
-    if constexpr (SK) {
-        const int total = p.sk_tiles * p.sk_slices;
-        int unit = tile0 * p.sk_len;
-        const int end = min(unit + p.sk_len, total);
-        bool first = true;
-        while (unit < end) {
-            const int t = unit / p.sk_slices, k_lo = unit - t * p.sk_slices;
-            const int len = min(p.sk_slices - k_lo, end - unit);
-            const int slab = tile0 - (t * p.sk_slices) / p.sk_len;     // workgroups that started this tile earlier
-            if (!first) __syncthreads();        // the previous segment's epilogue is done with the LDS
-            run_tile(t, slab, len, k_lo, false);
-            first = false;
-            unit += len;
-        }
-    } else {
-        run_tile(tile0, split0, split_len0, -1, tail0);
-    }
 }
 
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, int splits, int64_t n,
@@ -1673,8 +1631,6 @@ struct FixParams {
     int splits, rows, N, row0, ldc, flags;
     int perm_n, pq;      // position-major GEMM rows (see GemmParams::perm_n), positions per image
     int64_t stride;
-    // stream-K slabs (GemmParams::sk_*): the element's 128x128 tile decides how many slabs hold it
-    int sk_slices, sk_len, sk_ntn;
 };
 
 __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const FixParams f)
@@ -1683,13 +1639,8 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(const FixParams f)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)f.rows * n4) return;
     const int r = (int)(i / n4), c = (int)(i - (int64_t)r * n4) * 4;
-    int nsl = f.splits;
-    if (f.sk_len > 0) {
-        const int t = (r >> 7) * f.sk_ntn + (c >> 7);
-        nsl = ((t + 1) * f.sk_slices - 1) / f.sk_len - (t * f.sk_slices) / f.sk_len + 1;
-    }
     float4 a = *reinterpret_cast<const float4 *>(f.ws + (int64_t)r * f.N + c);
-    for (int s = 1; s < nsl; ++s) {
+    for (int s = 1; s < f.splits; ++s) {
         const float4 v = *reinterpret_cast<const float4 *>(f.ws + s * f.stride + (int64_t)r * f.N + c);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
@@ -1750,58 +1701,6 @@ void launch_split_rows(const GemmParams &p, int rows_lo, int splits, int total_s
                        s, f);
 }
 
-// Stream-K launch of a small-M forward-form problem (see SK): `wgs` workgroups, sk_len units each.
-template <int MODE>
-bool launch_stream_k(const GemmParams &p, int wgs, hipStream_t s)
-{
-    if constexpr (MODE != FWD) {
-        return false;
-    } else {
-        if (!(g_split_bf16 & 1) || is_masked(p) || !can_split_rows<MODE>(p) || p.perm_n > 0 || p.split_len != 0)
-            return false;
-        const int64_t tiles = mrcnn::ceil_div(p.M, 128) * mrcnn::ceil_div(p.N, 128);
-        const int slices = p.R * p.S * (int)mrcnn::ceil_div(p.Kc, BK);
-        const int64_t units = tiles * slices;
-        int len = (int)mrcnn::ceil_div(units, wgs);
-        if (len < 4 || units >= (int64_t)INT32_MAX) return false;
-        wgs = (int)mrcnn::ceil_div(units, len);
-        const int slabs = (int)mrcnn::ceil_div(slices, len) + 1;          // most workgroups that can touch one tile
-        const int64_t rows_pad = mrcnn::ceil_div(p.M, 128) * 128;
-        if (slabs > 16 || rows_pad * p.N * slabs * 4 > kSplitWsBytes) return false;
-        GemmParams q = p;
-        q.C = p.split_ws;
-        q.flags = 0;
-        q.bias = q.scale = q.shift = q.residual = q.res_g = q.res_y = q.out_mask_y = nullptr;
-        q.m_lo = 0;
-        q.split_len = 1;                      // (slab rows: the kernel takes the range length per segment)
-        q.split_stride = (int64_t)p.M * p.N;
-        q.out_row0 = 0;
-        q.c_bytes = (unsigned)(q.split_stride * 4);
-        q.sk_tiles = (int)tiles; q.sk_slices = slices; q.sk_len = len;
-        {
-            const double kdepth = (double)p.R * p.S * (double)p.Kc;
-            mrcnn::ProfKernelScope prof(mrcnn::PROF_CONV_FWD_64, 2.0 * p.M * p.N * kdepth,
-                                        4.0 * ((double)p.M * p.N + (double)p.M * p.Kc + (double)p.N * kdepth));
-            hipEvent_t ev0, ev1;
-            mrcnn::prof_take(&ev0, &ev1);
-            hipExtLaunchKernelGGL((conv_gemm_kernel<2, 2, FWD, false, false, true, true>), dim3((unsigned)wgs),
-                                  dim3(256), g_extra_lds, s, ev0, ev1, 0, q);
-        }
-        FixParams f = {};
-        f.ws = p.split_ws; f.C = p.C;
-        f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.residual = p.residual;
-        f.res_g = p.res_g; f.res_y = p.res_y; f.out_mask_y = p.out_mask_y;
-        f.splits = slabs; f.rows = p.M; f.N = p.N; f.row0 = 0; f.ldc = p.ldc;
-        f.flags = p.flags; f.stride = q.split_stride;
-        f.perm_n = 0; f.pq = p.gp * p.gq;
-        f.sk_slices = slices; f.sk_len = len; f.sk_ntn = (int)mrcnn::ceil_div(p.N, 128);
-        const int64_t n = (int64_t)p.M * (p.N / 4);
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0, s, f);
-        return true;
-    }
-}
-
-int g_stream_k = 0;                // mrcnn_set_tuning("stream_k"): 0 = off, k > 0 = workgroups of a stream-K launch (small-M forward form)
 int g_fused_tail = 512;            // mrcnn_set_tuning("fused_tail", 0 = off, else target number of tail pieces)
 
 // Rows [0, rows_main) as whole TMxTN tiles and rows [rows_main, p.M) as K-split pieces of the
@@ -1948,10 +1847,7 @@ int launch(const GemmParams &p0, int splits, hipStream_t s)
         }
         while (ksplits > 1 && (int64_t)p.M * p.N * ksplits * 4 > kSplitWsBytes) --ksplits;
     }
-    if (g_stream_k > 0 && big_ok && T < g_big_min_tiles && splits == 1 && p.N % 128 == 0 && total_slices_ >= 8 &&
-        launch_stream_k<MODE>(p, g_stream_k, s)) {
-        // (done)
-    } else if (ksplits >= 2) {
+    if (ksplits >= 2) {
         launch_split_rows<MODE, 2>(p, 0, (int)ksplits, total_slices_, s);
     } else if (!big_ok || T < g_big_min_tiles) {
         launch_small<MODE>(p, s);
@@ -2108,10 +2004,6 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "stagger") == 0) {
         g_stagger = value;
-        return 0;
-    }
-    if (strcmp(name, "stream_k") == 0) {
-        g_stream_k = value;
         return 0;
     }
     if (strcmp(name, "big_split_k") == 0) {
