@@ -454,7 +454,8 @@ def self_launch(args):
     (torch.distributed.run, rendezvous on 127.0.0.1) and pass their output through."""
     import subprocess
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    from chainer_mask_rcnn_amd import parallel
+    if n_dev < args.gpus and not (parallel.rehearsal() and n_dev >= 1):
         raise SystemExit('bench.py --gpus %d: only %d ROCm device(s) visible on this node; '
                          'one process per GPU is required (no oversubscription)'
                          % (args.gpus, n_dev))
@@ -1010,6 +1011,9 @@ def main():
                                      '2.35-2.39 GHz); the matrix pipe alone sustains 270 TFLOP/s of this '
                                      'arithmetic on random operands (profiles/r04_mfma_energy_probe.txt)'
                                      % (6 * ach))
+        if parallel.rehearsal():
+            out['rehearsal'] = ('MRCNN_DP_REHEARSAL=1: %d ranks SHARING one GPU, gradients over gloo — a run of '
+                                'the launch path, not a measurement' % world)
         if rotating is not None:
             out['rotating_h2d'] = rotating
         if pipeline is not None:

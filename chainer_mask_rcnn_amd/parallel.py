@@ -177,6 +177,10 @@ def default_exchange(group=None):
         return TorchDistExchange(group)
     import os
     import sys
+    if rehearsal():
+        ex = TorchDistExchange(group)
+        ex.fallback = 'MRCNN_DP_REHEARSAL=1: gloo on device tensors, ranks sharing one GPU (launch-path rehearsal)'
+        return ex
     ex, err = None, ''
     try:
         ex = RcclExchange()
@@ -400,6 +404,16 @@ class DataParallelGradSync(object):
         return d
 
 
+def rehearsal():
+    """``MRCNN_DP_REHEARSAL=1``: run the N-rank launch path on a box with FEWER GPUs than ranks — every
+    rank on device 0, the process group on gloo only, gradients through ``TorchDistExchange`` (gloo
+    moves device tensors through the host).  It exists to exercise everything around the RCCL calls
+    (rendezvous, rank-0 broadcast, bucket polling inside a real backward, deferred reductions, the
+    benchmark's fences and max-over-ranks) where RCCL itself cannot run (it refuses two ranks on one
+    device); never a measurement."""
+    return os.environ.get('MRCNN_DP_REHEARSAL') == '1'
+
+
 def init_from_env(backend=None):
     """One process per GPU, rendezvous from RANK / WORLD_SIZE / MASTER_* / LOCAL_RANK.
     The process group is the CONTROL plane (gloo; plus torch's nccl binding for device tensors
@@ -408,6 +422,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if rehearsal():
+        local, backend = 0, 'gloo'
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
