@@ -40,6 +40,8 @@ SIGNATURES = {
     'mrcnn_roi_align_fwd': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_f32, c_int, c_vp]),
     'mrcnn_roi_align_bwd': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 7 + [c_f32, c_int, c_vp]),
     'mrcnn_roi_align_fwd_ex': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 8 + [c_f32, c_int, c_vp, c_vp]),
+    'mrcnn_roi_align_fwd_affine': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 8 + [c_f32, c_int, c_vp, c_vp, c_vp,
+                                           c_int, c_vp]),
     'mrcnn_roi_align_bwd_workspace_bytes': (c_i64, [c_int] * 7),
     'mrcnn_sparse3x3_gather': (c_int, [c_vp, c_vp, c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp]),
     'mrcnn_sparse3x3_scatter': (c_int, [c_vp, c_vp] + [c_int] * 4 + [c_vp, c_vp]),

@@ -79,6 +79,24 @@ __device__ __forceinline__ void store_stream(float4 *p, float4 v)
     __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(p));
 }
 
+// Optional fused epilogue of the forward: y = relu?(v * scale[c] + shift[c]) — the AffineChannel2D
+// (+ ReLU) that follows a 1x1 convolution whose output is pooled (mrcnn_roi_align_fwd_affine).
+template <typename V> struct FwdEpi { V scale, shift; bool on, relu; };
+__device__ __forceinline__ float epi_apply(const FwdEpi<float> &e, float v)
+{
+    if (!e.on) return v;
+    v = v * e.scale + e.shift;
+    return e.relu ? fmaxf(v, 0.f) : v;
+}
+__device__ __forceinline__ float4 epi_apply(const FwdEpi<float4> &e, float4 v)
+{
+    if (!e.on) return v;
+    v = make_float4(v.x * e.scale.x + e.shift.x, v.y * e.scale.y + e.shift.y,
+                    v.z * e.scale.z + e.shift.z, v.w * e.scale.w + e.shift.w);
+    if (e.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    return v;
+}
+
 // acc / count exactly as the reference divides, without the ~10-instruction fp32 division per
 // component where it is not needed: count == 1 leaves acc, a power of two multiplies by its
 // (exact) reciprocal — the correctly rounded quotient and product of the same real number.
@@ -147,7 +165,7 @@ __device__ __forceinline__ float4 finish_mean<float4>(const float4 acc, int coun
 template <typename V, int GH, int GW, int NB>
 __device__ __forceinline__ void fwd_bins(const V *__restrict__ img, V *__restrict__ out,
                                          const RoiGeom &g, int ph, int ow0, int OW, int BS, int H,
-                                         int W, int CV)
+                                         int W, int CV, const FwdEpi<V> &epi)
 {
     constexpr int S = GH * GW;
     V v[NB][S][4];
@@ -202,7 +220,8 @@ __device__ __forceinline__ void fwd_bins(const V *__restrict__ img, V *__restric
             if (ok[b][s])
                 acc = VecOps<V>::mad4(acc, wt[b][s][0], v[b][s][0], wt[b][s][1], v[b][s][1],
                                       wt[b][s][2], v[b][s][2], wt[b][s][3], v[b][s][3]);
-        store_stream(&out[(int64_t)(ow0 + b) * CV], finish_mean<V>(acc, g.grid_h * g.grid_w, g.count));
+        store_stream(&out[(int64_t)(ow0 + b) * CV],
+                     epi_apply(epi, finish_mean<V>(acc, g.grid_h * g.grid_w, g.count)));
     }
 }
 
@@ -211,7 +230,7 @@ __device__ __forceinline__ void fwd_bins(const V *__restrict__ img, V *__restric
 template <typename V, int GW>
 __device__ __forceinline__ void fwd_bin_rows(const V *__restrict__ img, V *__restrict__ out,
                                              const RoiGeom &g, int ph, int ow_, int BS, int H, int W,
-                                             int CV)
+                                             int CV, const FwdEpi<V> &epi)
 {
     const int pw = ow_ * BS;
     V acc = VecOps<V>::zero();
@@ -271,7 +290,7 @@ __device__ __forceinline__ void fwd_bin_rows(const V *__restrict__ img, V *__res
             }
         }
     }
-    store_stream(&out[(int64_t)ow_ * CV], finish_mean<V>(acc, g.grid_h * g.grid_w, g.count));
+    store_stream(&out[(int64_t)ow_ * CV], epi_apply(epi, finish_mean<V>(acc, g.grid_h * g.grid_w, g.count)));
 }
 
 // V = float4 when C % 4 == 0 (CV = C/4 vectors per pixel), else float.
@@ -280,11 +299,13 @@ __device__ __forceinline__ void fwd_bin_rows(const V *__restrict__ img, V *__res
 // turnaround (0.24 of the HBM peak with 4 taps per bin); here the taps of up to four bins are in
 // flight together.  The sampling grid is a property of the RoI, so the choice among the
 // unrolled bodies is workgroup-uniform.
-template <typename V>
+template <typename V, bool EPI = false>
 __global__ void __launch_bounds__(256)
 roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois, V *__restrict__ y,
                      int H, int W, int CV, int PH, int PW, float spatial_scale, int sampling_ratio,
-                     int OH, int OW, int BS, int rows, const int *__restrict__ order)
+                     int OH, int OW, int BS, int rows, const int *__restrict__ order,
+                     const V *__restrict__ scale = nullptr, const V *__restrict__ shift = nullptr,
+                     int relu = 0)
 {
     // output bin (oh, ow) is bin (oh*BS, ow*BS) of the PH x PW grid (BS = 1: every bin)
     // an XCD (workgroup id mod 8) owns a contiguous run of rows (n*OH + oh): the OH rows of a
@@ -303,24 +324,28 @@ roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois, V 
     for (int c = threadIdx.x; c < CV; c += blockDim.x) {
         const V *__restrict__ img = x + (int64_t)g.batch * H * W * CV + c;
         V *__restrict__ out = y + ((int64_t)n * OH + oh) * OW * CV + c;
+        FwdEpi<V> epi;
+        epi.on = EPI;
+        epi.relu = EPI && relu != 0;
+        if constexpr (EPI) { epi.scale = scale[c]; epi.shift = shift[c]; }
         if (g.grid_h == 1 && g.grid_w == 1) {
-            for (int ow0 = 0; ow0 < OW; ow0 += 4) fwd_bins<V, 1, 1, 4>(img, out, g, ph, ow0, OW, BS, H, W, CV);
+            for (int ow0 = 0; ow0 < OW; ow0 += 4) fwd_bins<V, 1, 1, 4>(img, out, g, ph, ow0, OW, BS, H, W, CV, epi);
         } else if (g.grid_h == 1 && g.grid_w == 2) {
-            for (int ow0 = 0; ow0 < OW; ow0 += 2) fwd_bins<V, 1, 2, 2>(img, out, g, ph, ow0, OW, BS, H, W, CV);
+            for (int ow0 = 0; ow0 < OW; ow0 += 2) fwd_bins<V, 1, 2, 2>(img, out, g, ph, ow0, OW, BS, H, W, CV, epi);
         } else if (g.grid_h == 2 && g.grid_w == 1) {
-            for (int ow0 = 0; ow0 < OW; ow0 += 2) fwd_bins<V, 2, 1, 2>(img, out, g, ph, ow0, OW, BS, H, W, CV);
+            for (int ow0 = 0; ow0 < OW; ow0 += 2) fwd_bins<V, 2, 1, 2>(img, out, g, ph, ow0, OW, BS, H, W, CV, epi);
         } else if (g.grid_h == 2 && g.grid_w == 2) {
-            for (int ow0 = 0; ow0 < OW; ++ow0) fwd_bins<V, 2, 2, 1>(img, out, g, ph, ow0, OW, BS, H, W, CV);
+            for (int ow0 = 0; ow0 < OW; ++ow0) fwd_bins<V, 2, 2, 1>(img, out, g, ph, ow0, OW, BS, H, W, CV, epi);
         } else if (g.grid_w == 1) {
-            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 1>(img, out, g, ph, ow_, BS, H, W, CV);
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 1>(img, out, g, ph, ow_, BS, H, W, CV, epi);
         } else if (g.grid_w == 2) {
-            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 2>(img, out, g, ph, ow_, BS, H, W, CV);
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 2>(img, out, g, ph, ow_, BS, H, W, CV, epi);
         } else if (g.grid_w == 3) {
-            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 3>(img, out, g, ph, ow_, BS, H, W, CV);
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 3>(img, out, g, ph, ow_, BS, H, W, CV, epi);
         } else if (g.grid_w == 4) {
-            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 4>(img, out, g, ph, ow_, BS, H, W, CV);
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 4>(img, out, g, ph, ow_, BS, H, W, CV, epi);
         } else {
-            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 0>(img, out, g, ph, ow_, BS, H, W, CV);
+            for (int ow_ = 0; ow_ < OW; ++ow_) fwd_bin_rows<V, 0>(img, out, g, ph, ow_, BS, H, W, CV, epi);
         }
     }
 }
@@ -635,7 +660,10 @@ roi_align_bwd_owner_kernel(const V *__restrict__ gy, const int4 *__restrict__ ex
     const int nb = OH * OW;
     const int cap = 2 * nthr;
 
-    for (int c0 = 0; c0 < CV; c0 += nthr) {
+    // (one channel chunk of nthr lanes per workgroup: blockIdx.y — the 2048-channel gradients of the
+    // projected head would otherwise build the tile's lists once per chunk in sequence)
+    {
+        const int c0 = (int)blockIdx.y * nthr;
         const int c = c0 + tid;
         const bool cok = c < CV;
         const V *__restrict__ top = gy + (cok ? c : 0);
@@ -790,13 +818,16 @@ int check_args(const void *a, const void *b, const void *c, int N, int H, int W,
 
 }  // namespace
 
-extern "C" int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *y, int N, int H,
-                                      int W, int C, int R, int PH, int PW, int bin_stride,
-                                      float spatial_scale, int sampling_ratio, const int *order,
-                                      void *stream)
+namespace {
+int roi_align_fwd_launch(const float *x, const float *rois, float *y, int N, int H, int W, int C, int R,
+                         int PH, int PW, int bin_stride, float spatial_scale, int sampling_ratio,
+                         const int *order, const float *scale, const float *shift, int relu,
+                         void *stream)
 {
     if (int rc = check_args(x, rois, y, N, H, W, C, R, PH, PW, sampling_ratio)) return rc;
     MRCNN_REQUIRE(bin_stride >= 1, "roi_align: bin_stride must be >= 1");
+    const bool epi = scale != nullptr || shift != nullptr;
+    MRCNN_REQUIRE(!epi || (scale && shift), "roi_align_fwd_affine: scale and shift go together");
     if (R == 0) return 0;
     const int OH = (PH + bin_stride - 1) / bin_stride, OW = (PW + bin_stride - 1) / bin_stride;
     const int bins = R * OH * OW;
@@ -805,18 +836,52 @@ extern "C" int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *
     hipEvent_t ev0, ev1;      // kernel-only timing from the dispatch packet (bench.py roofline)
     mrcnn::prof_begin_ext(mrcnn::PROF_ROI_ALIGN_FWD, 0.,
                           4.0 * ((double)bins * C + (double)N * H * W * C), &ev0, &ev1);
-    if (C % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0)) {
+    const dim3 grid((R * OH + 7) / 8 * 8);
+    const bool vec = C % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
+                     (!epi || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)));
+    if (vec) {
         const int cv = C / 4;
-        hipExtLaunchKernelGGL(roi_align_fwd_kernel<float4>, dim3((R * OH + 7) / 8 * 8),
-                              dim3(pick_threads(cv)), 0, s, ev0, ev1, 0, (const float4 *)x, rois,
-                              (float4 *)y, H, W, cv, PH, PW, spatial_scale, sampling_ratio, OH, OW,
-                              bin_stride, R * OH, order);
+        if (epi)
+            hipExtLaunchKernelGGL((roi_align_fwd_kernel<float4, true>), grid, dim3(pick_threads(cv)), 0, s,
+                                  ev0, ev1, 0, (const float4 *)x, rois, (float4 *)y, H, W, cv, PH, PW,
+                                  spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH, order,
+                                  (const float4 *)scale, (const float4 *)shift, relu);
+        else
+            hipExtLaunchKernelGGL((roi_align_fwd_kernel<float4, false>), grid, dim3(pick_threads(cv)), 0, s,
+                                  ev0, ev1, 0, (const float4 *)x, rois, (float4 *)y, H, W, cv, PH, PW,
+                                  spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH, order,
+                                  (const float4 *)nullptr, (const float4 *)nullptr, 0);
+    } else if (epi) {
+        hipExtLaunchKernelGGL((roi_align_fwd_kernel<float, true>), grid, dim3(pick_threads(C)), 0, s, ev0,
+                              ev1, 0, x, rois, y, H, W, C, PH, PW, spatial_scale, sampling_ratio, OH, OW,
+                              bin_stride, R * OH, order, scale, shift, relu);
     } else {
-        hipExtLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3((R * OH + 7) / 8 * 8),
-                              dim3(pick_threads(C)), 0, s, ev0, ev1, 0, x, rois, y, H, W, C, PH, PW,
-                              spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH, order);
+        hipExtLaunchKernelGGL((roi_align_fwd_kernel<float, false>), grid, dim3(pick_threads(C)), 0, s, ev0,
+                              ev1, 0, x, rois, y, H, W, C, PH, PW, spatial_scale, sampling_ratio, OH, OW,
+                              bin_stride, R * OH, order, (const float *)nullptr, (const float *)nullptr, 0);
     }
     return mrcnn::check_launch("roi_align_fwd");
+}
+}  // namespace
+
+extern "C" int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *y, int N, int H,
+                                      int W, int C, int R, int PH, int PW, int bin_stride,
+                                      float spatial_scale, int sampling_ratio, const int *order,
+                                      void *stream)
+{
+    return roi_align_fwd_launch(x, rois, y, N, H, W, C, R, PH, PW, bin_stride, spatial_scale,
+                                sampling_ratio, order, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mrcnn_roi_align_fwd_affine(const float *x, const float *rois, float *y, int N, int H,
+                                          int W, int C, int R, int PH, int PW, int bin_stride,
+                                          float spatial_scale, int sampling_ratio, const int *order,
+                                          const float *scale, const float *shift, int relu,
+                                          void *stream)
+{
+    MRCNN_REQUIRE(scale && shift, "roi_align_fwd_affine: null scale / shift");
+    return roi_align_fwd_launch(x, rois, y, N, H, W, C, R, PH, PW, bin_stride, spatial_scale,
+                                sampling_ratio, order, scale, shift, relu, stream);
 }
 
 extern "C" int mrcnn_roi_align_fwd(const float *x, const float *rois, float *y, int N, int H,
@@ -893,7 +958,8 @@ extern "C" int mrcnn_roi_align_bwd_ws(const float *gy, const float *rois, float 
         hipExtLaunchKernelGGL(roi_bwd_tables_kernel, dim3(R), dim3(256), 0, s, ev0, nullptr, 0, rois, H,
                               W, w.Wp, PH, PW, OH, OW, bin_stride, spatial_scale, sampling_ratio, ext,
                               Ay, Bx);
-        const dim3 grid((unsigned)((tiles + 7) / 8 * 8));
+        const int nthr = pick_threads(vec ? C / 4 : C);
+        const dim3 grid((unsigned)((tiles + 7) / 8 * 8), (unsigned)(((vec ? C / 4 : C) + nthr - 1) / nthr));
         if (vec)
             hipExtLaunchKernelGGL(roi_align_bwd_owner_kernel<float4>, grid, dim3(pick_threads(C / 4)),
                                   0, s, nullptr, ev1, 0, (const float4 *)gy, ext, Ay, Bx, (float4 *)gx,

@@ -848,6 +848,69 @@ SMALL_WGRAD_MAX_PIXELS = int(_os.environ.get('MRCNN_SIDE_WGRAD_MAX_PIXELS', 4000
 PRETRANSPOSE_FILTERS = False
 
 
+# ---- pooling AFTER res5.a's 1x1 projections ("projected pooling") --------------------------------
+# The RoI head applies ROIAlign to the C4 feature map and then res5 (models/mask_rcnn_resnet.py:
+# 168-176), whose first block reads the pooled map only through two 1x1 convolutions (conv1 and the
+# shortcut conv4, each followed by AffineChannel2D).  ROIAlign is linear over positions per channel
+# with no constant term, a bias-free 1x1 convolution is linear over channels per position: they
+# commute exactly,
+#     bn(conv1x1(roi_align(x))) == bn(roi_align(conv1x1(x))),
+# so both projections run on the N*H*W map pixels (2 x 51 x 84 = 8 568 at the C2 shape) instead of
+# the R*7*7 pooled ones (50 176), and ROIAlign pools their 512- / 2048-channel outputs with the
+# affine (+ ReLU) in its epilogue.  Backward likewise: ROIAlign's adjoint first, then data and
+# weight gradient of the projections on the map.  Same sums in a different order (fp32 rounding
+# only); PROJECTED_POOLING = False restores the reference order.
+PROJECTED_POOLING = _os.environ.get('MRCNN_PROJECTED_POOLING', '1') != '0'
+
+
+class RoiSpec(object):
+    """What ``building_block(..., roi=)`` needs to pool inside the stage node: ``rois`` (R, 5) float32
+    device rows (batch, x1, y1, x2, y2), the pooled size ``outh`` x ``outw`` of the FULL bin grid,
+    ``bin_stride`` (the stride of block a's 1x1 convolutions: only those bins are produced) and the
+    optional processing ``order`` (functions.roi_align_2d.spatial_order)."""
+
+    def __init__(self, rois, outh, outw, spatial_scale, bin_stride=1, order=None, sampling_ratio=0):
+        self.rois = rois.contiguous()
+        self.outh, self.outw = int(outh), int(outw)
+        self.spatial_scale = float(spatial_scale)
+        self.bin_stride = int(bin_stride)
+        self.order = order
+        self.sampling_ratio = int(sampling_ratio)
+
+    @property
+    def out_hw(self):
+        bs = self.bin_stride
+        return (self.outh + bs - 1) // bs, (self.outw + bs - 1) // bs
+
+
+def _roi_pool_affine(z, roi, scale, shift, relu):
+    """relu?(roi_align(z) * scale + shift) for an NHWC map ``z`` (N, C, H, W logical)."""
+    N, C, H, W = z.shape
+    R = roi.rois.shape[0]
+    oh, ow = roi.out_hw
+    y = empty_nhwc((R, C, oh, ow), z.device)
+    order = roi.order if R > 0 else None
+    _lib.call('mrcnn_roi_align_fwd_affine', _lib.ptr(z), _lib.ptr(roi.rois), _lib.ptr(y), N, H, W, C, R,
+              roi.outh, roi.outw, roi.bin_stride, roi.spatial_scale, roi.sampling_ratio,
+              _lib.ptr(order) if order is not None else None, _lib.ptr(scale), _lib.ptr(shift),
+              1 if relu else 0, _lib.stream_ptr())
+    return y
+
+
+def _roi_pool_bwd(g, roi, map_shape):
+    """ROIAlign's adjoint: g (R, C, oh, ow) -> (N, C, H, W), pixel-owner form (no atomics)."""
+    N, C, H, W = map_shape
+    R = roi.rois.shape[0]
+    gz = empty_nhwc((N, C, H, W), g.device)
+    nbytes = _lib.load().mrcnn_roi_align_bwd_workspace_bytes(N, H, W, R, roi.outh, roi.outw, roi.bin_stride)
+    ws = _lib.workspace(nbytes, g.device, 'roi_align_bwd')
+    _lib.call('mrcnn_roi_align_bwd_ws', _lib.ptr(g), _lib.ptr(roi.rois), _lib.ptr(gz), N, H, W, C, R,
+              roi.outh, roi.outw, roi.bin_stride, roi.spatial_scale, roi.sampling_ratio, _lib.ptr(ws),
+              int(ws.numel() * ws.element_size()), _lib.stream_ptr())
+    return gz
+
+
+
 # set by building_block() around _StageFn.apply: inside forward() grad mode is always off and
 # ctx.needs_input_grad reports the inputs' requires_grad flags even under torch.no_grad()
 _STAGE_RECORDS_GRAPH = True
@@ -856,8 +919,11 @@ _STAGE_RECORDS_GRAPH = True
 class _StageFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, strides, proj, poll, tail_rows, *params):
-        """``strides[i]`` / ``proj[i]``: conv1(/conv4) stride and has-projection flag of block
+    def forward(ctx, x, strides, proj, poll, tail_rows, roi, *params):
+        """``roi`` (a ``RoiSpec`` or None): with it ``x`` is the FEATURE MAP and block 0 (which must
+        have a projection shortcut) runs its two 1x1 convolutions on the map and pools their outputs
+        (projected pooling, see above) — the stage then equals ``stage(roi_align(x, roi))``.
+        ``strides[i]`` / ``proj[i]``: conv1(/conv4) stride and has-projection flag of block
         i; ``poll``: optional callable invoked during backward at the stage's entry and after
         every block's weight gradients have been queued (parallel.DataParallelGradSync launches
         the gradient buckets that are complete); ``tail_rows``: None, or an int64 index tensor —
@@ -870,19 +936,28 @@ class _StageFn(torch.autograd.Function):
         x = nhwc(x)
         blocks, saved, pos, wino_v = [], [x], 0, []
         h = x
-        for stride, pj in zip(strides, proj):
+        if roi is not None:
+            if not (proj[0] and strides[0] == 1 and params[0].shape[2] == 1 and params[9].shape[2] == 1):
+                raise ValueError('projected pooling needs a first block with 1x1 conv1 / conv4 at stride 1 '
+                                 '(the RoI bins of the stride are selected by RoiSpec.bin_stride)')
+        for bi, (stride, pj) in enumerate(zip(strides, proj)):
             n = 12 if pj else 9
             W1, s1, b1, W2, s2, b2, W3, s3, b3 = params[pos:pos + 9]
             W4, s4, b4 = params[pos + 9:pos + 12] if pj else (None, None, None)
+            pooled_here = roi is not None and bi == 0
             d1 = make_desc(h.shape, W1.shape, stride, 0)
-            h1 = _fwd_raw(h, nhwc(W1), d1, s1, b1, None, True)
+            if pooled_here:
+                # conv1 on the map, then pooled with bn1 + ReLU in ROIAlign's epilogue
+                h1 = _roi_pool_affine(_fwd_raw(h, nhwc(W1), d1, None, None, None, False), roi, s1, b1, True)
+            else:
+                h1 = _fwd_raw(h, nhwc(W1), d1, s1, b1, None, True)
             d2 = make_desc(h1.shape, W2.shape, 1, 1)
             v2 = None
             training = _STAGE_RECORDS_GRAPH and any(ctx.needs_input_grad)
             if uses_winograd(d2) and (WINOGRAD_TRAIN_FORWARD in (True, 'stage') or not training):
                 # (with a weight gradient to come, the transformed input is kept for it)
                 h2, v2 = wino_fwd(h1, nhwc(W2), d2, s2, b2, True,
-                                  keep_v=training and bool(ctx.needs_input_grad[5 + pos + 3]),
+                                  keep_v=training and bool(ctx.needs_input_grad[6 + pos + 3]),
                                   cache_for=None if training else W2,
                                   exact_signs=training and WINOGRAD_EXACT_SIGNS)
             else:
@@ -890,7 +965,11 @@ class _StageFn(torch.autograd.Function):
             d4 = None
             if pj:
                 d4 = make_desc(h.shape, W4.shape, stride, 0)
-                shortcut = _fwd_raw(h, nhwc(W4), d4, s4, b4, None, False)
+                if pooled_here:
+                    shortcut = _roi_pool_affine(_fwd_raw(h, nhwc(W4), d4, None, None, None, False),
+                                                roi, s4, b4, False)
+                else:
+                    shortcut = _fwd_raw(h, nhwc(W4), d4, s4, b4, None, False)
             else:
                 shortcut = h
             d3 = make_desc(h2.shape, W3.shape, 1, 0)
@@ -905,6 +984,7 @@ class _StageFn(torch.autograd.Function):
         ctx.blocks = blocks
         ctx.proj = tuple(proj)
         ctx.poll = poll
+        ctx.roi = roi
         ctx.n_saved = len(saved)
         ctx.wino_slots = [i for i, v in enumerate(wino_v) if v is not None]
         ctx.save_for_backward(*(saved + [wino_v[i] for i in ctx.wino_slots]))
@@ -996,14 +1076,23 @@ class _StageFn(torch.autograd.Function):
             x, h1, h2, y, s1, s2, s3, s4 = acts[i]
             (d1, d2, d3, d4), (W1, W2, W3, W4), p0 = ctx.blocks[i]
             wT = stage_wT[i]
-            base = 5 + p0                      # index of W1 among the forward inputs
+            base = 6 + p0                      # index of W1 among the forward inputs
             first = i == 0
+            pooled_here = first and ctx.roi is not None
             # what the gradient leaving this block must be masked with: the previous block's
             # output ReLU (= this block's input); the stage input belongs to someone else
             xm = None if first else x
             if ng[base + 6]:
                 grads[base + 6] = _wgrad_raw(d3, h2, gm, W3, None, None, side, row_scale=s3)
-            if W4 is not None and ng[base + 9]:
+            gz4 = None
+            if pooled_here:
+                # the shortcut's gradient back on the map (ROIAlign's adjoint commutes with the
+                # per-channel scale s4, which stays folded into conv4's filter / gradient rows)
+                if ng[base + 9] or ng[0]:
+                    gz4 = _roi_pool_bwd(gm, ctx.roi, (x.shape[0], d4.K, x.shape[2], x.shape[3]))
+                if ng[base + 9]:
+                    grads[base + 9] = _wgrad_raw(d4, x, gz4, W4, None, None, side, row_scale=s4)
+            elif W4 is not None and ng[base + 9]:
                 grads[base + 9] = _wgrad_raw(d4, x, gm, W4, None, None, side, row_scale=s4)
             gh2 = _dgrad_raw(d3, gm, nhwc(W3), None, None, fold_scale=s3,
                              out_mask_y=h2, out_scale=s2, wT=wT.get('3'))
@@ -1023,12 +1112,19 @@ class _StageFn(torch.autograd.Function):
                     grads[base + 3] = _wgrad_raw(d2, h1, gh2, W2, None, None, side)
                 gh1 = _dgrad_raw(d2, gh2, nhwc(W2), None, None, out_mask_y=h1, out_scale=s1,
                                  wT=wT.get('2'))
+            if pooled_here and (ng[base] or ng[0]):
+                gh1 = _roi_pool_bwd(gh1, ctx.roi, (x.shape[0], d1.K, x.shape[2], x.shape[3]))
             if ng[base]:
                 grads[base] = _wgrad_raw(d1, x, gh1, W1, None, None, side)
             if poll is not None:
                 poll()             # this block's weight gradients are queued
             if first and not ng[0]:
                 break
+            if pooled_here:
+                gx = _dgrad_raw(d1, gh1, nhwc(W1), None, None, wT=wT.get('1'))
+                gm = _dgrad_raw(d4, gz4, nhwc(W4), None, None, fold_scale=s4, out=gx, accum=True,
+                                wT=wT.get('4'))
+                continue
             if W4 is None:
                 gm = _dgrad_raw(d1, gh1, nhwc(W1), None, None, res_g=gm, out_mask_y=xm,
                                 wT=wT.get('1'))
@@ -1046,10 +1142,11 @@ class _StageFn(torch.autograd.Function):
         return tuple(grads)
 
 
-def building_block(x, blocks, first_stride=None, poll=None, tail_rows=None):
+def building_block(x, blocks, first_stride=None, poll=None, tail_rows=None, roi=None):
     """A chain of Bottleneck links (chainer BuildingBlock) as one fused autograd node.  With
     ``tail_rows`` (int64 row indices) it returns ``(average_pooling_2d(y, map size), y[tail_rows])``
-    instead of y — see _StageFn.forward."""
+    instead of y — see _StageFn.forward.  With ``roi`` (a ``RoiSpec``) ``x`` is the feature map and
+    the result is ``building_block(roi_align(x, roi), ...)`` (projected pooling)."""
     strides, proj, params = [], [], []
     for i, b in enumerate(blocks):
         strides.append(b.conv1.stride if not (i == 0 and first_stride is not None) else first_stride)
@@ -1061,6 +1158,6 @@ def building_block(x, blocks, first_stride=None, poll=None, tail_rows=None):
     global _STAGE_RECORDS_GRAPH
     _STAGE_RECORDS_GRAPH = torch.is_grad_enabled()
     try:
-        return _StageFn.apply(x, tuple(strides), tuple(proj), poll, tail_rows, *params)
+        return _StageFn.apply(x, tuple(strides), tuple(proj), poll, tail_rows, roi, *params)
     finally:
         _STAGE_RECORDS_GRAPH = True

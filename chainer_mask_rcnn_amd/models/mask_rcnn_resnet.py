@@ -69,6 +69,10 @@ class ResNetRoIHead(torch.nn.Module):
         self.spatial_scale = spatial_scale
         self.pooling_func = pooling_func
         self.fused_tail = True      # developer switch: res5's two consumers inside the stage node
+        # Pool BEHIND res5.a's 1x1 projections instead of in front of them (functions/conv.py
+        # "projected pooling": the same values up to fp32 rounding, the two projections on the map's
+        # pixels instead of the pooled ones).  None = follow functions.conv.PROJECTED_POOLING.
+        self.projected_pooling = None
 
     def forward(self, x, rois, roi_indices, pred_bbox=True, pred_mask=True, mask_rows=None):
         """Reference: models/mask_rcnn_resnet.py:168-196.
@@ -85,7 +89,17 @@ class ResNetRoIHead(torch.nn.Module):
         fused_tail = pred_bbox and pred_mask and mask_rows is not None and \
             getattr(self.res5, 'fused_stage', False) and self.fused_tail
         kw = dict(tail_rows=mask_rows) if fused_tail else {}
-        if res5_stride > 1 and self.pooling_func is functions.roi_align_2d:
+        from ..functions import conv as _conv
+        projected = self.projected_pooling if self.projected_pooling is not None else _conv.PROJECTED_POOLING
+        if projected and self.pooling_func is functions.roi_align_2d and \
+                getattr(self.res5, 'fused_stage', False) and rois.shape[0] > 0:
+            # the stage node pools inside block a: conv1 / conv4 (1x1, stride s) read only the bins
+            # (s*i, s*j) of the pooled map, and they commute with ROIAlign
+            order = getattr(rois, '_mrcnn_order', None)
+            spec = _conv.RoiSpec(indices_and_rois[:, [0, 2, 1, 4, 3]], self.roi_size, self.roi_size,
+                                 self.spatial_scale, bin_stride=res5_stride, order=order)
+            res5 = self.res5(x, first_stride=1, roi=spec, **kw)
+        elif res5_stride > 1 and self.pooling_func is functions.roi_align_2d:
             # res5.a reads the pooled map only through 1x1 stride-s convolutions (conv1 and
             # the shortcut conv4), i.e. only the bins (s*i, s*j): pool just those and run the
             # block with stride 1 — same values, a quarter of the ROIAlign work and traffic.

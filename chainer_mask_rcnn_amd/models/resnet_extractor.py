@@ -99,15 +99,17 @@ class BuildingBlock(torch.nn.Module):
         # block): parallel.DataParallelGradSync launches completed gradient buckets from it
         self.grad_poll = None
 
-    def forward(self, x, first_stride=None, tail_rows=None):
+    def forward(self, x, first_stride=None, tail_rows=None, roi=None):
         """``first_stride`` overrides the stride of block ``a`` (used by the RoI head when the
         stride-2 subsampling has already been done by the pooling op).  ``tail_rows`` (fused
-        stage only): return ``(average_pooling_2d(y), y[tail_rows])`` instead of y."""
+        stage only): return ``(average_pooling_2d(y), y[tail_rows])`` instead of y.  ``roi`` (fused
+        stage only; a ``functions.conv.RoiSpec``): ``x`` is the feature map and the stage pools
+        inside block ``a``, behind its 1x1 projections (functions/conv.py "projected pooling")."""
         if self.fused_stage:
             return F.building_block(x, [getattr(self, n) for n in self._names], first_stride,
-                                    poll=self.grad_poll, tail_rows=tail_rows)
-        if tail_rows is not None:
-            raise ValueError('tail_rows needs the fused stage')
+                                    poll=self.grad_poll, tail_rows=tail_rows, roi=roi)
+        if tail_rows is not None or roi is not None:
+            raise ValueError('tail_rows / roi need the fused stage')
         for name in self._names:
             if name == 'a' and first_stride is not None:
                 x = self.a(x, stride=first_stride)

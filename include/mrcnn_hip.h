@@ -80,6 +80,20 @@ int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *y,
                            int N, int H, int W, int C, int R, int PH, int PW, int bin_stride,
                            float spatial_scale, int sampling_ratio, const int *order,
                            void *stream);
+/* ROIAlign with a fused per-channel epilogue: y = relu?(roi_align(x) * scale[c] + shift[c]).
+ * Used where the head pools the OUTPUT of res5.a's 1x1 convolutions instead of their input
+ * (models/mask_rcnn_resnet.py:131-133, 168-176: ROIAlign, then conv1 / the shortcut conv4, each 1x1,
+ * followed by AffineChannel2D (+ ReLU)).  ROIAlign is linear over positions per channel and has no
+ * constant term (skipped samples contribute zero, functions/roi_align_2d.py:228-236), a 1x1
+ * convolution without bias is linear over channels per position, so
+ *     affine(conv1x1(roi_align(x))) == affine(roi_align(conv1x1(x)))
+ * in exact arithmetic: the convolution runs on the N*H*W map pixels instead of the R*7*7 pooled
+ * ones (8 568 instead of 50 176 rows at the C2 shape) and this call applies the AffineChannel2D
+ * (scale, shift: C floats each, both required) and the ReLU to the pooled values. */
+int mrcnn_roi_align_fwd_affine(const float *x, const float *rois, float *y,
+                               int N, int H, int W, int C, int R, int PH, int PW, int bin_stride,
+                               float spatial_scale, int sampling_ratio, const int *order,
+                               const float *scale, const float *shift, int relu, void *stream);
 /* Backward, two forms.  ws = NULL (and mrcnn_roi_align_bwd): gather form with one atomic add
  * per (RoI patch pixel, channel) into a zero-filled gx — the order of the fp32 additions, like
  * the reference's atomicAdd kernel (:508-515), varies from run to run.  ws = a 16-byte aligned
