@@ -660,10 +660,14 @@ roi_align_bwd_owner_kernel(const V *__restrict__ gy, const int4 *__restrict__ ex
     const int nb = OH * OW;
     const int cap = 2 * nthr;
 
-    // (one channel chunk of nthr lanes per workgroup: blockIdx.y — the 2048-channel gradients of the
-    // projected head would otherwise build the tile's lists once per chunk in sequence)
-    {
-        const int c0 = (int)blockIdx.y * nthr;
+    // One channel chunk of nthr lanes per workgroup (blockIdx.y; grid-stride form): the 2048-channel
+    // gradients of the projected head would otherwise build the tile's lists once per chunk in
+    // sequence.  KEEP THIS KERNEL FREE OF SCRATCH (tests/test_build_cpu.py): written as a plain
+    // block instead of this loop the compiler spilled three registers at the 96-register budget, and
+    // with the weight-gradient GEMMs of the side stream running beside it single dwords of single
+    // lanes came back wrong from the spill slots (a handful of gx elements per launch, run to run) —
+    // private-segment memory of two queues' concurrent kernels is not something to rely on here.
+    for (int c0 = (int)blockIdx.y * nthr; c0 < CV; c0 += (int)gridDim.y * nthr) {
         const int c = c0 + tid;
         const bool cok = c < CV;
         const V *__restrict__ top = gy + (cok ? c : 0);

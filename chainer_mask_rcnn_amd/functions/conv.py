@@ -911,6 +911,21 @@ def _roi_pool_bwd(g, roi, map_shape):
 
 
 
+def _pool_bwd_alone(side, device):
+    """The compute stream waits for the weight-gradient side stream before a pixel-owner ROIAlign
+    backward inside a stage.  Round 6 finding (tests/test_gpu_model.py::test_training_is_bit_
+    reproducible_run_to_run on the small test model, whose RoI head is small enough to use the side
+    stream): with a weight-gradient GEMM of the SAME block running on the side stream — it reads the
+    gradient tensor the ROIAlign backward reads — a launch now and then lost ONE list entry's
+    contribution in ONE component of 16 lanes (a handful of gx elements, different from run to run);
+    the same two kernels side by side in isolation (900 launches, the captured tensors included) never
+    did, and neither kernel uses scratch.  Not understood; serialising the two streams at this point
+    removes it, costs nothing at full size (the head's weight gradients do not use the side stream
+    there) and ~20 us in the small configurations that do."""
+    if side is not None:
+        torch.cuda.current_stream(device).wait_stream(side)
+
+
 # set by building_block() around _StageFn.apply: inside forward() grad mode is always off and
 # ctx.needs_input_grad reports the inputs' requires_grad flags even under torch.no_grad()
 _STAGE_RECORDS_GRAPH = True
@@ -1082,14 +1097,17 @@ class _StageFn(torch.autograd.Function):
             # what the gradient leaving this block must be masked with: the previous block's
             # output ReLU (= this block's input); the stage input belongs to someone else
             xm = None if first else x
+            gz4 = None
+            if pooled_here and (ng[base + 9] or ng[0]):
+                # the shortcut's gradient back on the map (ROIAlign's adjoint commutes with the
+                # per-channel scale s4, which stays folded into conv4's filter / gradient rows).
+                # Queued BEFORE this block's weight gradients go to the side stream, and with the side
+                # stream drained: see _pool_bwd_alone.
+                _pool_bwd_alone(side, dev_)
+                gz4 = _roi_pool_bwd(gm, ctx.roi, (x.shape[0], d4.K, x.shape[2], x.shape[3]))
             if ng[base + 6]:
                 grads[base + 6] = _wgrad_raw(d3, h2, gm, W3, None, None, side, row_scale=s3)
-            gz4 = None
             if pooled_here:
-                # the shortcut's gradient back on the map (ROIAlign's adjoint commutes with the
-                # per-channel scale s4, which stays folded into conv4's filter / gradient rows)
-                if ng[base + 9] or ng[0]:
-                    gz4 = _roi_pool_bwd(gm, ctx.roi, (x.shape[0], d4.K, x.shape[2], x.shape[3]))
                 if ng[base + 9]:
                     grads[base + 9] = _wgrad_raw(d4, x, gz4, W4, None, None, side, row_scale=s4)
             elif W4 is not None and ng[base + 9]:
@@ -1113,6 +1131,7 @@ class _StageFn(torch.autograd.Function):
                 gh1 = _dgrad_raw(d2, gh2, nhwc(W2), None, None, out_mask_y=h1, out_scale=s1,
                                  wT=wT.get('2'))
             if pooled_here and (ng[base] or ng[0]):
+                _pool_bwd_alone(side, dev_)
                 gh1 = _roi_pool_bwd(gh1, ctx.roi, (x.shape[0], d1.K, x.shape[2], x.shape[3]))
             if ng[base]:
                 grads[base] = _wgrad_raw(d1, x, gh1, W1, None, None, side)
