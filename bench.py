@@ -101,9 +101,11 @@ def build_trainer(n_layers, device, world, lr_batch, force_dp=False, bucket_byte
         # hold the weight gradients (+ update) of the first res5 block's 3x3 / 1x1 back into the
         # next step's proposal window, where the GPU is otherwise nearly idle (optimizers.py)
         a, b1, b2 = model.head.res5.a, model.head.res5.b1, model.head.res5.b2
-        opt.defer_weight_gradients([a.conv2.W, a.conv1.W, a.conv3.W, a.conv4.W, b1.conv2.W,
-                                    b1.conv1.W, b1.conv3.W, b2.conv2.W, b2.conv1.W,
-                                    b2.conv3.W][:defer])
+        # (res5.a's conv1 / conv4 come last: with projected pooling their weight gradients are
+        # map-sized, a tenth of the others)
+        opt.defer_weight_gradients([a.conv2.W, a.conv3.W, b1.conv2.W, b1.conv1.W, b1.conv3.W,
+                                    b2.conv2.W, b2.conv1.W, b2.conv3.W, a.conv1.W,
+                                    a.conv4.W][:defer])
     return model, chain, opt, sync
 
 
@@ -515,7 +517,7 @@ def main():
                     help='skip the `r101` (BASELINE configs[3] per GPU) and `infer` (configs[4]) measurements '
                          'that follow the headline on single-GPU ResNet-50 runs')
     ap.add_argument('--defer-wgrad', type=int, default=5,
-                    help='number of res5 weight gradients (a.conv2, a.conv1, a.conv3, a.conv4, b1.conv2, ...) held back into the '
+                    help='number of res5 weight gradients (a.conv2, a.conv3, b1.conv2, b1.conv1, b1.conv3, ...) held back into the '
                          "next step's proposal window (single-GPU runs; 0 = off)")
     ap.add_argument('--no-fp32-mfma', '--no-split-bf16', dest='fp32_mfma', action='store_false',
                     help='skip the extra measurement on the fp32-MFMA GEMM kernels (the default arithmetic '
