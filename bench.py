@@ -161,24 +161,33 @@ def fg_saturated_sampler(base):
 class SmiSampler(object):
     """Package power and shader clock sampled on a host thread while a timed region runs
     (librocm_smi64 through ctypes: rsmi_dev_power_get / rsmi_dev_gpu_clk_freq_get, one sample every
-    `period` seconds — a `rocm-smi` subprocess takes longer than the 0.5 s region).  The chip clocks
+    `period` seconds (10 Hz: a handful of SMU queries per timed region, `--no-smi` turns it off — same-box A/B
+    in profiles/r06_smi_ab.txt; a `rocm-smi` subprocess takes longer than the 0.5 s region).  The chip clocks
     to its power budget (MI355X_MICROARCH.md "DVFS give-back"): a throughput number without the clock
     and power it was measured at cannot be compared across boxes.  Reported only; every failure
     (library missing, sensor unsupported) yields None fields, never an exception."""
 
-    def __init__(self, index=0, period=0.01):
+    def __init__(self, index=0, period=0.1, enabled=True):
         import threading
         self.index, self.period = index, period
         self.samples = []            # (seconds, watts or None, MHz or None)
         self._stop = threading.Event()
         self._thread = None
         self.lib = None
+        self._power = self._clk = None
+        if not enabled:
+            return
         try:
             lib = ctypes.CDLL('librocm_smi64.so')
-            if lib.rsmi_init(ctypes.c_uint64(0)) == 0:
+            # every symbol resolved HERE: a library without one of them disables the sampler
+            # instead of raising inside the sampling thread
+            init = getattr(lib, 'rsmi_init')
+            self._power = getattr(lib, 'rsmi_dev_power_get')
+            self._clk = getattr(lib, 'rsmi_dev_gpu_clk_freq_get')
+            if init(ctypes.c_uint64(0)) == 0:
                 self.lib = lib
-        except OSError:
-            pass
+        except (OSError, AttributeError):
+            self.lib = None
 
     class _Freq(ctypes.Structure):
         _fields_ = [('has_deep_sleep', ctypes.c_bool), ('num_supported', ctypes.c_uint32),
@@ -189,10 +198,10 @@ class SmiSampler(object):
         if self.lib is None:
             return watts, mhz
         p, kind = ctypes.c_uint64(0), ctypes.c_int(0)
-        if self.lib.rsmi_dev_power_get(ctypes.c_uint32(self.index), ctypes.byref(p), ctypes.byref(kind)) == 0:
+        if self._power(ctypes.c_uint32(self.index), ctypes.byref(p), ctypes.byref(kind)) == 0:
             watts = p.value / 1e6
         f = self._Freq()
-        if self.lib.rsmi_dev_gpu_clk_freq_get(ctypes.c_uint32(self.index), ctypes.c_int(0), ctypes.byref(f)) == 0 \
+        if self._clk(ctypes.c_uint32(self.index), ctypes.c_int(0), ctypes.byref(f)) == 0 \
                 and f.current < 33:
             mhz = f.frequency[f.current] / 1e6
         return watts, mhz
@@ -429,6 +438,43 @@ def bench_infer(args, device, rank, steps=None, warmup=None):
     return None
 
 
+def preflight_allreduce(exchange, rank, world, device, timeout_s=60.0):
+    """Before any timed work of a multi-GPU run: ONE 4-float all-reduce through the gradient exchange
+    (RCCL behind mrcnn_allreduce_* on an N-GPU node) with a host-side deadline.  A rank whose
+    communicator did not come up, or whose peers never arrive, shows up HERE — with the rank named on
+    stderr and a non-zero exit — instead of as a hang inside the first training step's bucket."""
+    import threading
+    t = torch.full((4,), float(rank + 1), dtype=torch.float32, device=device)
+    done, err = threading.Event(), []
+
+    def run():
+        try:
+            exchange.allreduce_async(t, -3)
+            exchange.wait_all()
+            torch.cuda.synchronize(device)
+        except Exception as e:        # noqa: BLE001  (reported below, with the rank)
+            err.append(e)
+        done.set()
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    if not done.wait(timeout_s):
+        sys.stderr.write('bench.py pre-flight: rank %d of %d did not complete a 4-float all-reduce within %.0f s '
+                         '(%s); peers that are missing never reached the rendezvous\n'
+                         % (rank, world, timeout_s, exchange.describe()))
+        sys.stderr.flush()
+        os._exit(3)
+    if err:
+        raise SystemExit('bench.py pre-flight: rank %d of %d: all-reduce failed: %r' % (rank, world, err[0]))
+    want = world * (world + 1) / 2.0
+    got = t.cpu().numpy()
+    if not np.all(got == want):
+        raise SystemExit('bench.py pre-flight: rank %d of %d: all-reduce returned %s, expected %s (%s)'
+                         % (rank, world, got.tolist(), want, exchange.describe()))
+    if rank == 0:
+        sys.stderr.write('bench.py pre-flight: %d-rank all-reduce ok (%s)\n' % (world, exchange.describe()))
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -482,6 +528,8 @@ def main():
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=1333)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-smi', dest='smi', action='store_false',
+                    help='do not sample package power / shader clock during the timed regions')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--lr-batch', type=int, default=0,
                     help='override the global batch the learning-rate rule uses (developer: '
@@ -596,6 +644,8 @@ def main():
                                             bucket_bytes=parallel_bucket_bytes,
                                             defer=args.defer_wgrad)
     imgs_d = torch.tensor(imgs, device=device).contiguous(memory_format=torch.channels_last)
+    if sync is not None and world > 1:
+        preflight_allreduce(sync.exchange, rank, world, device)
 
     if args.prefetch_frozen:
         chain.next_imgs = imgs_d       # resident batch: the next iteration's images are known
@@ -635,7 +685,7 @@ def main():
     # `roofline`.
     R = max(1, args.repeats)
     region_s = []
-    smi = SmiSampler(local)
+    smi = SmiSampler(local, enabled=args.smi)
     with smi:
         for _ in range(R):
             t0 = time.perf_counter()

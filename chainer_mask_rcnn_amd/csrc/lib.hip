@@ -22,7 +22,7 @@ thread_local ProfPending g_prof_pending;
 namespace {
 struct ProfRec { hipEvent_t start, stop; int kind; double flops, bytes; };
 std::mutex g_prof_mu;
-int g_prof_mode = 0;   // 0 off, 1 every kind, 2 only the dominant kind
+int g_prof_mode = 0;   // 0 off, 1 every kind timed, 2 only the dominant kind (+ ROIAlign) timed, 3 counting only
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_event_pool;
 hipEvent_t get_event()
@@ -100,6 +100,8 @@ static const char *kProfNames[mrcnn::PROF_NUM_KINDS] = {
 
 extern "C" int mrcnn_profile_enable(int on)
 {
+    MRCNN_REQUIRE(on >= 0 && on <= 3, "profile_enable: mode must be 0 (off), 1 (every kind timed), 2 (dominant "
+                                      "kinds timed) or 3 (launches / flops / bytes counted, nothing timed), got %d", on);
     std::lock_guard<std::mutex> lk(mrcnn::g_prof_mu);
     for (auto &r : mrcnn::g_prof_recs) {
         if (r.start) mrcnn::g_event_pool.push_back(r.start);

@@ -23,6 +23,7 @@ MI355X-first design
 """
 import ctypes
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -423,6 +424,18 @@ def init_from_env(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
     if rehearsal():
+        # A leaked MRCNN_DP_REHEARSAL=1 on a real multi-GPU node would put every rank on device 0 and
+        # move the gradients through the host without an error: refuse where one GPU per rank exists.
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if world > 1 and n_dev >= world:
+            raise RuntimeError(
+                'MRCNN_DP_REHEARSAL=1 with WORLD_SIZE=%d on a node with %d visible GPUs: the rehearsal '
+                'mode (every rank on device 0, gradients over gloo) is for boxes with FEWER GPUs than '
+                'ranks; unset it to run one rank per GPU over RCCL' % (world, n_dev))
+        if rank == 0:
+            sys.stderr.write('[chainer_mask_rcnn_amd] MRCNN_DP_REHEARSAL=1: %d rank(s) share device 0 and '
+                             'exchange gradients over gloo through the host — a launch-path rehearsal, '
+                             'never a measurement\n' % world)
         local, backend = 0, 'gloo'
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -44,7 +44,8 @@ int mrcnn_device_info(int *n_cu, char *name, int name_len);
  * reports).  mrcnn_profile_enable(mode) clears the records; mode 0 = off, 1 = every kind,
  * 2 = only the forward-form 128x128 conv GEMM, the dominant kernel symbol (~48 instead of
  * ~500 event pairs per train step, so the timed region is barely perturbed; the other kinds
- * still count launches / flops / bytes);
+ * still count launches / flops / bytes), 3 = count launches / flops / bytes of every kind and
+ * time nothing (no events on the stream at all); any other value is an error.
  * mrcnn_profile_summary sums the records (synchronise the stream first). */
 int mrcnn_profile_enable(int on);
 int mrcnn_profile_num_kinds(void);

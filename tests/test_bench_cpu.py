@@ -20,13 +20,29 @@ def test_smi_sampler_without_a_device_reports_none():
 
 
 def test_bench_refuses_to_run_without_a_rocm_device():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0',
-                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=300)
     import torch
     if torch.cuda.is_available():
-        return
+        return                       # (a GPU box: nothing to refuse, and a full bench run is not a CPU test)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0',
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ''          # no JSON line from a run that measured nothing
     assert 'ROCm device' in r.stderr or 'HIP' in r.stderr or 'hip' in r.stderr
+
+
+def test_smi_sampler_can_be_disabled_and_survives_a_library_without_the_symbols(monkeypatch):
+    s = bench.SmiSampler(0, enabled=False)
+    with s:
+        pass
+    assert s.lib is None and s.summary()['samples'] == 0
+
+    class NoSymbols(object):          # a librocm_smi64 that lacks the two query functions
+        def __getattr__(self, name):
+            raise AttributeError(name)
+    monkeypatch.setattr(bench.ctypes, 'CDLL', lambda name: NoSymbols())
+    s = bench.SmiSampler(0)
+    with s:
+        pass
+    assert s.lib is None and s.summary()['power_w'] is None
 
 
 def test_multi_gpu_request_without_devices_is_refused():

@@ -19,7 +19,10 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2,
+                                 reason='a node with a GPU per rank runs tests/test_gpu_parallel_rccl.py instead: '
+                                        'the rehearsal mode (two ranks on one device over gloo) refuses to start there')]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LR, WD = 0.002, 1e-4

@@ -11,11 +11,20 @@ rounding of zero on ANY seed (tools/pick_step_fixture_seeds.py: 24 of 24 seed pa
 tensor beyond 1e-4 on BOTH arithmetics) — one flipped decision moves a patch of every gradient below
 it by 1e-4 .. 1e-2 of its scale.  The entrywise statement is therefore made in its well-posed form,
 for EVERY trainable tensor and with no exemption, on both arithmetics:
+  (0) the oracle step run at test time IS the committed artifact: its six losses and every committed
+      `grad/*` array agree with the fixture to 1e-6 / 1e-5 of the tensor's scale (BLAS summation
+      order on another host; on the generating host they are bit-identical) — the fixture, not the
+      test-time run, stays the arbiter;
   (1) the HIP step's ReLU decisions differ from the oracle's only at units whose oracle
-      pre-activation lies within 1e-4 of the site's scale of zero, fewer than 1 in 100 000 of them;
+      pre-activation lies within 1e-5 of the site's scale of zero (about ten fp32 roundings), at
+      most 16 of the ~4e7 units; the flips are printed per site;
   (2) GIVEN the decisions (the oracle step re-evaluated with the HIP step's decisions,
       oracle/np_step.RELU_FORCE), every gradient entry and the six losses agree to 1e-4.
-When no decision differs, (2) is the comparison with the committed fixture itself."""
+When no decision differs, (2) is the comparison with the committed fixture itself.
+
+Unconditionally (no decision conditioning at all) on the configuration where no decision differs:
+the fp32-MFMA arithmetic in the reference's operation order (ROIAlign before res5.a's projections,
+`test_fp32_reference_order_matches_fixture_entrywise`)."""
 import os
 
 import numpy as np
@@ -85,6 +94,45 @@ def _hip_decisions(tap):
     return out
 
 
+DECISION_WINDOW = 1e-5      # |oracle pre-activation| / site scale below which a decision may differ
+MAX_FLIPS = 16              # absolute cap over all ~4e7 units with a backward
+
+
+def _assert_oracle_is_the_fixture(free, d):
+    """The oracle step run at test time reproduces the committed artifact (losses 1e-6 relative,
+    committed gradient arrays 1e-5 of their scale: BLAS summation order on another host)."""
+    for k, v in zip(d['loss_names'], d['loss_values']):
+        got = float(free['losses'][str(k)])
+        assert abs(got - v) <= 1e-6 * max(abs(v), 1e-3), ('oracle vs fixture', k, got, v)
+    n = 0
+    for key in d.files:
+        if key.startswith('grad/'):
+            scale = np.abs(d[key]).max()
+            assert np.abs(free['grads'][key[5:]] - d[key]).max() <= 1e-5 * scale, ('oracle vs fixture', key)
+            n += 1
+    assert n > 0
+    for k, l2 in zip(d['grad_names'], d['grad_l2']):
+        g = np.sqrt(np.sum(free['grads'][str(k)].astype(np.float64) ** 2))
+        assert abs(g - l2) <= 1e-5 * l2 + 1e-12, ('oracle vs fixture', k, g, l2)
+
+
+def _compare_decisions(hip, pre):
+    n_units = n_diff = 0
+    worst, flips = 0., {}
+    for site, m in hip.items():
+        p_ = pre[site]
+        assert m.shape == p_.shape, (site, m.shape, p_.shape)
+        diff = m != (p_ > 0)
+        n_units += m.size
+        if diff.any():
+            n_diff += int(diff.sum())
+            flips[site] = int(diff.sum())
+            w = float(np.abs(p_[diff]).max() / np.abs(p_).max())
+            worst = max(worst, w)
+            assert w <= DECISION_WINDOW, (site, w)
+    return n_units, n_diff, worst, flips
+
+
 _ORACLE_FREE = {}
 
 
@@ -130,22 +178,12 @@ def test_hip_train_step_matches_fixture(dev, golden_dir, arithmetic):
         _ORACLE_FREE['out'] = _oracle_step(inputs, record=pre)
         _ORACLE_FREE['pre'] = pre
     free, pre = _ORACLE_FREE['out'], _ORACLE_FREE['pre']
+    _assert_oracle_is_the_fixture(free, d)
     assert sorted(hip) == sorted(pre), (sorted(set(hip) ^ set(pre)))
-    n_units = n_diff = 0
-    worst = 0.
-    for site, m in hip.items():
-        p_ = pre[site]
-        assert m.shape == p_.shape, (site, m.shape, p_.shape)
-        diff = m != (p_ > 0)
-        n_units += m.size
-        n_diff += int(diff.sum())
-        if diff.any():
-            w = float(np.abs(p_[diff]).max() / np.abs(p_).max())
-            worst = max(worst, w)
-            assert w <= 1e-4, (site, w)
-    print('%s: %d of %d ReLU decisions differ from the oracle\'s, all within %.1e of the site scale of zero'
-          % (arithmetic, n_diff, n_units, worst))
-    assert n_diff <= 1e-5 * n_units
+    n_units, n_diff, worst, flips = _compare_decisions(hip, pre)
+    print('%s: %d of %d ReLU decisions differ from the oracle\'s, all within %.1e of the site scale of zero; '
+          'per site: %s' % (arithmetic, n_diff, n_units, worst, flips))
+    assert n_diff <= MAX_FLIPS, flips
 
     # (2) every gradient entry, given the decisions
     if n_diff == 0:
@@ -166,3 +204,36 @@ def test_hip_train_step_matches_fixture(dev, golden_dir, arithmetic):
     print('%s: worst gradient entry vs %s: %.2e of the tensor scale (%s), %d tensors'
           % (arithmetic, what, worst, worst_name, len(ref['grads'])))
     assert worst <= 1e-4, (worst_name, worst)
+
+
+def test_fp32_reference_order_matches_fixture_entrywise(dev, golden_dir):
+    """No decision conditioning: the fp32-MFMA arithmetic in the reference's operation order
+    (projected pooling off) takes every ReLU decision of the fixture's step, and EVERY committed
+    gradient array agrees with the fixture entry by entry to 1e-4 of its scale."""
+    from chainer_mask_rcnn_amd.functions import conv as C_
+    d = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    saved = C_.PROJECTED_POOLING
+    C_.set_gemm_arithmetic('fp32')
+    C_.PROJECTED_POOLING = False
+    try:
+        model, chain, tap, rng_after, inputs = _hip_step(dev, with_tap=True)
+    finally:
+        C_.PROJECTED_POOLING = saved
+        C_.set_gemm_arithmetic(C_.DEFAULT_GEMM_ARITHMETIC)
+    hip = _hip_decisions(tap)
+    del tap[:]
+    if 'out' not in _ORACLE_FREE:
+        pre = {}
+        _ORACLE_FREE['out'] = _oracle_step(inputs, record=pre)
+        _ORACLE_FREE['pre'] = pre
+    _assert_oracle_is_the_fixture(_ORACLE_FREE['out'], d)
+    n_units, n_diff, worst, flips = _compare_decisions(hip, _ORACLE_FREE['pre'])
+    assert n_diff == 0, flips
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
+    n = 0
+    for key in d.files:
+        if key.startswith('grad/'):
+            scale = np.abs(d[key]).max()
+            assert np.abs(grads[key[5:]] - d[key]).max() <= 1e-4 * scale, key
+            n += 1
+    assert n > 0 and rng_after == int(d['np_random_after'])

@@ -334,3 +334,23 @@ def test_eight_rank_rehearsal_on_the_resnet50_arena():
     assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] == [] for r in res), res      # (numbers of the failed checks per rank)
     assert len(set(r[2] for r in res)) == 1
+
+
+def test_rehearsal_mode_refuses_a_node_with_a_gpu_per_rank(monkeypatch, capsys):
+    """A leaked MRCNN_DP_REHEARSAL=1 must not silently put every rank on device 0 of a real multi-GPU
+    node (parallel.init_from_env): refused when >= WORLD_SIZE devices are visible, announced on stderr
+    otherwise."""
+    from chainer_mask_rcnn_amd import parallel
+    monkeypatch.setenv('MRCNN_DP_REHEARSAL', '1')
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    with pytest.raises(RuntimeError, match='FEWER GPUs than'):
+        parallel.init_from_env()
+    # fewer devices than ranks: allowed, and loud
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    monkeypatch.setattr(parallel.dist, 'is_initialized', lambda: True)      # (no rendezvous in this test)
+    rank, world, local = parallel.init_from_env()
+    assert (rank, world, local) == (0, 2, 0)
+    assert 'MRCNN_DP_REHEARSAL=1' in capsys.readouterr().err
