@@ -580,6 +580,7 @@ def weights_changed():
     True)``) does not bump ``_version`` either.  Drops every cached transformed filter; the
     serializers call it, and so must any other out-of-band writer."""
     _wino_u_cache.clear()
+    _proj_cache.clear()
 
 
 # The cache has no cross-stream ordering: an entry is produced and read on the caller's current
@@ -869,7 +870,11 @@ class RoiSpec(object):
     ``bin_stride`` (the stride of block a's 1x1 convolutions: only those bins are produced) and the
     optional processing ``order`` (functions.roi_align_2d.spatial_order)."""
 
-    def __init__(self, rois, outh, outw, spatial_scale, bin_stride=1, order=None, sampling_ratio=0):
+    def __init__(self, rois, outh, outw, spatial_scale, bin_stride=1, order=None, sampling_ratio=0,
+                 proj=None):
+        # ``proj`` (inference only): the two projections of the map, ``projected_map(...)``, when the
+        # caller pools several RoI sets from one map (MaskRCNN.predict_prepared: one head call per image)
+        self.proj = proj
         self.rois = rois.contiguous()
         self.outh, self.outw = int(outh), int(outw)
         self.spatial_scale = float(spatial_scale)
@@ -881,6 +886,29 @@ class RoiSpec(object):
     def out_hw(self):
         bs = self.bin_stride
         return (self.outh + bs - 1) // bs, (self.outw + bs - 1) // bs
+
+
+# The projections of one feature map, kept while the SAME map is pooled again without a graph
+# (inference runs the head once per image and once per mask group on one batch's map): the map
+# tensor itself is held so that its identity cannot be recycled; ``weights_changed`` drops the entry.
+_proj_cache = {}
+
+
+def projected_map(x, W1, W4):
+    """(conv1x1(x, W1), conv1x1(x, W4)) of an NHWC map, bias-free and without epilogue — the inputs
+    ``RoiSpec(proj=)`` takes.  Cached per (map, filters) while autograd is off."""
+    x = nhwc(x)
+    key = (id(x), x._version, x.data_ptr(), tuple(x.shape), id(W1), W1._version, W1.data_ptr(),
+           id(W4), W4._version, W4.data_ptr())
+    hit = _proj_cache.get('entry')
+    if hit is not None and hit[0] == key:
+        return hit[2], hit[3]
+    d1 = make_desc(x.shape, W1.shape, 1, 0)
+    d4 = make_desc(x.shape, W4.shape, 1, 0)
+    z1 = _fwd_raw(x, nhwc(W1), d1, None, None, None, False)
+    z4 = _fwd_raw(x, nhwc(W4), d4, None, None, None, False)
+    _proj_cache['entry'] = (key, x, z1, z4)
+    return z1, z4
 
 
 def _roi_pool_affine(z, roi, scale, shift, relu):
@@ -952,6 +980,9 @@ class _StageFn(torch.autograd.Function):
         blocks, saved, pos, wino_v = [], [x], 0, []
         h = x
         if roi is not None:
+            if roi.proj is not None and _STAGE_RECORDS_GRAPH and any(ctx.needs_input_grad):
+                raise ValueError('RoiSpec(proj=) is for graph-free calls (the projections would be '
+                                 'outside the recorded graph)')
             if not (proj[0] and strides[0] == 1 and params[0].shape[2] == 1 and params[9].shape[2] == 1):
                 raise ValueError('projected pooling needs a first block with 1x1 conv1 / conv4 at stride 1 '
                                  '(the RoI bins of the stride are selected by RoiSpec.bin_stride)')
@@ -963,7 +994,9 @@ class _StageFn(torch.autograd.Function):
             d1 = make_desc(h.shape, W1.shape, stride, 0)
             if pooled_here:
                 # conv1 on the map, then pooled with bn1 + ReLU in ROIAlign's epilogue
-                h1 = _roi_pool_affine(_fwd_raw(h, nhwc(W1), d1, None, None, None, False), roi, s1, b1, True)
+                z1 = roi.proj[0] if roi.proj is not None else _fwd_raw(h, nhwc(W1), d1, None, None, None, False)
+                h1 = _roi_pool_affine(z1, roi, s1, b1, True)
+                del z1
             else:
                 h1 = _fwd_raw(h, nhwc(W1), d1, s1, b1, None, True)
             d2 = make_desc(h1.shape, W2.shape, 1, 1)
@@ -981,8 +1014,9 @@ class _StageFn(torch.autograd.Function):
             if pj:
                 d4 = make_desc(h.shape, W4.shape, stride, 0)
                 if pooled_here:
-                    shortcut = _roi_pool_affine(_fwd_raw(h, nhwc(W4), d4, None, None, None, False),
-                                                roi, s4, b4, False)
+                    z4 = roi.proj[1] if roi.proj is not None else _fwd_raw(h, nhwc(W4), d4, None, None, None, False)
+                    shortcut = _roi_pool_affine(z4, roi, s4, b4, False)
+                    del z4
                 else:
                     shortcut = _fwd_raw(h, nhwc(W4), d4, s4, b4, None, False)
             else:

@@ -96,8 +96,13 @@ class ResNetRoIHead(torch.nn.Module):
             # the stage node pools inside block a: conv1 / conv4 (1x1, stride s) read only the bins
             # (s*i, s*j) of the pooled map, and they commute with ROIAlign
             order = getattr(rois, '_mrcnn_order', None)
+            # without a graph (predict: one head call per image and per mask group on ONE map) the
+            # two projections of the map are computed once and kept until the map or the weights change
+            pre = None
+            if not (torch.is_grad_enabled() and (x.requires_grad or self.res5.a.conv1.W.requires_grad)):
+                pre = _conv.projected_map(x, self.res5.a.conv1.W, self.res5.a.conv4.W)
             spec = _conv.RoiSpec(indices_and_rois[:, [0, 2, 1, 4, 3]], self.roi_size, self.roi_size,
-                                 self.spatial_scale, bin_stride=res5_stride, order=order)
+                                 self.spatial_scale, bin_stride=res5_stride, order=order, proj=pre)
             res5 = self.res5(x, first_stride=1, roi=spec, **kw)
         elif res5_stride > 1 and self.pooling_func is functions.roi_align_2d:
             # res5.a reads the pooled map only through 1x1 stride-s convolutions (conv1 and

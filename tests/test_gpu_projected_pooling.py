@@ -229,3 +229,34 @@ def test_head_switch_gives_the_same_predictions(dev):
             outs[projected] = [t.cpu().numpy() for t in head(x, rois, idx)]
     for a, b in zip(outs[False], outs[True]):
         assert np.abs(a - b).max() <= 1e-4 * np.abs(a).max()
+
+
+def test_inference_keeps_the_projected_map_across_head_calls(dev):
+    """predict runs the head once per image on ONE batch map: without a graph the two projections of
+    the map are computed once (functions.conv.projected_map), reused by the next call on the same
+    map, dropped by weights_changed(), and never used when a graph is recorded."""
+    import chainer_mask_rcnn_amd as cmr
+    torch.manual_seed(0)
+    head = cmr.models.mask_rcnn_resnet.ResNetRoIHead(50, 5, 14, 1 / 16.).to(dev)
+    x = nhwc(torch.randn((2, 1024, 13, 17), device=dev))      # as the extractor hands it over: channels-last
+    rng = np.random.RandomState(1)
+    r5 = _rois(rng, 20, 2, 13, 17)
+    rois = torch.tensor(r5[:, [2, 1, 4, 3]], device=dev)
+    idx = torch.tensor(r5[:, 0].astype(np.int32), device=dev)
+    C.weights_changed()
+    with torch.no_grad():
+        whole = [t.cpu().numpy() for t in head(x, rois, idx)]
+        entry = C._proj_cache['entry']
+        parts = [head(x, rois[lo:hi], idx[lo:hi]) for lo, hi in ((0, 7), (7, 20))]
+        assert C._proj_cache['entry'] is entry            # same map, same filters: reused
+    for k in range(3):
+        got = np.concatenate([p[k].cpu().numpy() for p in parts], 0)
+        # rows of the head are independent (the tile / K-split policy follows the row count: fp32 rounding)
+        assert np.abs(got - whole[k]).max() <= 1e-5 * np.abs(whole[k]).max()
+    C.weights_changed()
+    assert 'entry' not in C._proj_cache
+    xg = x.clone().requires_grad_(True)
+    out = head(xg, rois, idx)
+    assert 'entry' not in C._proj_cache                    # recorded graph: projections inside the node
+    out[0].sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
