@@ -158,6 +158,34 @@ def fg_saturated_sampler(base):
     return obj
 
 
+def trained_regime_sampler(base, img_hw):
+    """Benchmark workload device (not product code): `fg_saturated_sampler` whose candidate list holds,
+    instead of the random-init RPN's proposals (3 - 10 feature pixels high on the synthetic batch: 94 %
+    of them sample ONE point per bin), as many OBJECT-SIZED boxes — 32 .. 600 px on a side, uniformly
+    placed, the generator of tools/exp/roi_align_probe.py — next to the jittered ground-truth copies:
+    the foreground cap of 128 is reached AND the adaptive sampling grid of ROIAlign
+    (/root/reference/chainer_mask_rcnn/functions/roi_align_2d.py:91-96: ceil(roi size / 14)) grows to
+    2 x 2 .. 3 x 3 as it does on a trained model's proposals.  Private RandomState: the global np.random
+    stream is consumed exactly as before."""
+    sat = fg_saturated_sampler(base)
+    cls = type(sat)
+    H, W = img_hw
+
+    class TrainedRegime(cls):
+        _boxes = np.random.RandomState(777)
+
+        def _more(self, roi, bbox):
+            n = len(roi)
+            hh, ww = self._boxes.uniform(32, 600, n), self._boxes.uniform(32, 600, n)
+            y0, x0 = self._boxes.uniform(0, H - 32, n), self._boxes.uniform(0, W - 32, n)
+            obj = np.stack([y0, x0, np.minimum(y0 + hh, H), np.minimum(x0 + ww, W)], 1).astype(np.float32)
+            return cls._more(self, obj, bbox)
+
+    obj = TrainedRegime.__new__(TrainedRegime)
+    obj.__dict__.update(sat.__dict__)
+    return obj
+
+
 class SmiSampler(object):
     """Package power and shader clock sampled on a host thread while a timed region runs
     (librocm_smi64 through ctypes: rsmi_dev_power_get / rsmi_dev_gpu_clk_freq_get, one sample every
@@ -254,31 +282,37 @@ def profile_summary():
 
 
 def roi_align_isolated(chain, device, reps=20):
-    """ROIAlign forward / backward ALONE on the GPU on the RoIs the last timed step sampled (same
-    shapes, bin stride and processing order as the model's call), timed by the in-library HIP
-    events.  Inside the step the two kernels run beside the deferred weight gradients of the
-    proposal window; this is what the kernels do with the GPU to themselves."""
-    import importlib
+    """The ROIAlign kernels ALONE on the GPU on the RoIs the last timed step sampled, in the
+    configuration the head runs them in (projected pooling: the forward pools the 512-channel conv1
+    map with bn1 + ReLU in its epilogue and the 2048-channel conv4 map with bn4, the pixel-owner
+    backward takes the two gradients back to the map; bin stride and processing order as in the
+    model's call), timed by the in-library HIP events.  Inside the step they share the GPU with
+    other streams' work; this is what the kernels do with the GPU to themselves."""
     from chainer_mask_rcnn_amd import _lib
-    ra = importlib.import_module('chainer_mask_rcnn_amd.functions.roi_align_2d')
+    from chainer_mask_rcnn_amd.functions import conv as C
+    from chainer_mask_rcnn_amd.functions._layout import nhwc
     lib = _lib.load()
     t = chain.last_targets
     rois, idx, shape = t['sample_rois'], t['sample_roi_indices'], t['feature_shape']
     head = chain.mask_rcnn.head
     order = getattr(rois, '_mrcnn_order', None)
-    x = torch.randn(shape, device=device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     r5 = torch.cat((idx.to(torch.float32)[:, None], rois), 1)[:, [0, 2, 1, 4, 3]].contiguous()
     bs = max(1, head.roi_size // 7)
-    gy = None
+    spec = C.RoiSpec(r5, head.roi_size, head.roi_size, head.spatial_scale, bin_stride=bs, order=order)
+    N, _, H, W = shape
+    a = head.res5.a
+    maps = [(nhwc(torch.randn((N, a.conv1.W.shape[0], H, W), device=device)), a.bn1.W, a.bn1.b, True),
+            (nhwc(torch.randn((N, a.conv4.W.shape[0], H, W), device=device)), a.bn4.W, a.bn4.b, False)]
+    gys = None
     for it in range(reps + 3):
         if it == 3:
             torch.cuda.synchronize()
             lib.mrcnn_profile_enable(1)
-        y = ra._ROIAlign2DFn.apply(x, r5, head.roi_size, head.roi_size, head.spatial_scale, 0, bs, order)
-        if gy is None:
-            gy = torch.randn_like(y)
-        x.grad = None
-        y.backward(gy)
+        ys = [C._roi_pool_affine(z, spec, sc, sh, relu) for z, sc, sh, relu in maps]
+        if gys is None:
+            gys = [torch.randn_like(y) for y in ys]
+        for (z, _, _, _), gy in zip(maps, gys):
+            C._roi_pool_bwd(gy, spec, tuple(z.shape))
     torch.cuda.synchronize()
     prof = profile_summary()
     lib.mrcnn_profile_enable(0)
@@ -795,6 +829,40 @@ def main():
                          loss=round(float(loss_c.item()), 5))
         chain.proposal_target_creator = ptc0
 
+    # ---- the regime a trained model runs in: foreground cap AND object-sized proposals ---------------
+    trained = None
+    if args.fg_capped:
+        ptc0 = chain.proposal_target_creator
+        chain.proposal_target_creator = trained_regime_sampler(ptc0, (args.height, args.width))
+        for _ in range(max(2, args.warmup)):
+            step()
+        fence()
+        lib.mrcnn_profile_enable(2) if not args.no_profile else None    # (ROIAlign launches event-timed)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_t = step()
+        fence()
+        el_t = max_over_ranks(time.perf_counter() - t0)
+        prof_t = {} if args.no_profile else profile_summary()
+        lib.mrcnn_profile_enable(0)
+        hbm_t = {k: dict(gbs=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9, 1),
+                         frac_of_hbm_peak=round(v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                         avg_launch_us=round(v['total_ms'] * 1e3 / v['launches'], 1))
+                 for k, v in prof_t.items() if k.startswith('roi_align') and v['total_ms'] > 0}
+        sr = chain.last_targets['sample_rois'].cpu().numpy()
+        side = np.sqrt(np.maximum(sr[:, 2] - sr[:, 0], 1) * np.maximum(sr[:, 3] - sr[:, 1], 1))
+        trained = dict(value=round(args.steps * args.batch * world / el_t, 3), unit='images/sec',
+                       ms_per_step=round(el_t / args.steps * 1e3, 3),
+                       fg_rois_per_image=chain.last_targets['n_fg'] / float(args.batch),
+                       roi_side_px_percentiles=[round(float(v), 1) for v in np.percentile(side, [5, 50, 95])],
+                       hbm_kernels=hbm_t,
+                       hbm_kernels_isolated=roi_align_isolated(chain, device) if not args.no_profile else None,
+                       workload='same step; the sampler sees object-sized candidate boxes (32 .. 600 px a side) '
+                                'and jittered ground-truth copies: 128 foreground RoIs per image and ROIAlign '
+                                'sampling grids of 2 x 2 .. 3 x 3, the regime of a trained model',
+                       loss=round(float(loss_t.item()), 5))
+        chain.proposal_target_creator = ptc0
+
     # ---- the same step with the target creators' arithmetic on the device ----------
     dev_targets = None
     if args.device_targets:
@@ -1072,6 +1140,8 @@ def main():
             out['pipeline_h2d'] = pipeline
         if fg_capped is not None:
             out['fg_capped'] = fg_capped
+        if trained is not None:
+            out['trained_regime'] = trained
         if dev_targets is not None:
             out['device_targets'] = dev_targets
         if wino_fwd is not None:

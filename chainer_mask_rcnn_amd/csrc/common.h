@@ -92,4 +92,7 @@ static inline void prof_take(hipEvent_t *start, hipEvent_t *stop)
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// roi_align.hip's share of mrcnn_set_tuning ("roi_fwd_lanes", "roi_bwd_lanes"); 0 = name handled
+int roi_align_set_tuning(const char *name, int value);
+
 }  // namespace mrcnn

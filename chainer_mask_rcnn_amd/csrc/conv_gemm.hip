@@ -362,19 +362,32 @@ __device__ __forceinline__ void sgb_interleave()
     }
 }
 
-template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false>
-__global__ void __launch_bounds__(256, SPLIT ? (TM == 2 ? 2 : 4) : min_blocks(TM, MODE, MASKED))
+// W8 (round 6; SPLIT forward form only): ONE 512-thread workgroup per CU on a 256 x 128 tile — eight
+// waves of 64 x 64, i.e. the two co-resident 128 x 128 workgroups of the standard configuration
+// stacked on top of each other so that they share the filter panel: 48 instead of 64 operand loads
+// and 3/4 of the split arithmetic per CU and K slice.  Two LDS stages, ONE barrier per slice.  What
+// two independent workgroups get from drifting apart — one stages while the other multiplies — the
+// two halves of this workgroup get from running the barrier interval in OPPOSITE ORDER: waves 0-3
+// multiply slice k and then split / store slice k + 1, waves 4-7 store first and multiply afterwards
+// (both orders read stage k & 1 and write the other one, so the interval needs no further
+// synchronisation); a SIMD hosts one wave of each half (MI355X_MICROARCH.md, wave placement).
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false, bool W8 = false>
+__global__ void __launch_bounds__(W8 ? 512 : 256,
+                                  SPLIT ? (TM == 2 ? 2 : 4) : min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
 {
+    static_assert(!W8 || (SPLIT && MODE == FWD && TM == 2 && TN == 2 && !MASKED),
+                  "W8: the split-operand forward form on 64x64 wave tiles, unmasked");
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
     constexpr bool ILV = MRCNN_SPLIT_ILV != 0 && SPLIT && MODE == FWD && !MASKED;
     static_assert(!SPLIT || (BK == 32 && TM == TN &&
                              ((MODE == FWD && (TM == 1 || TM == 2)) || (MODE == WGRAD && !WPERM && TM == 2))),
                   "SPLIT: forward form (128x128, 64x64) / weight gradient (128x128) only");
-    constexpr bool SINGLEBUF = SPLIT || single_buffered(TM, MODE, MASKED);
+    constexpr bool SINGLEBUF = !W8 && (SPLIT || single_buffered(TM, MODE, MASKED));
     using C_ = Cfg<TM, TN, MODE>;
-    constexpr int BM = C_::BM, BN = C_::BN;
-    constexpr int AV = C_::A_V4, BV = C_::B_V4;
+    constexpr int NT = W8 ? 512 : 256;                  // threads of the workgroup
+    constexpr int BM = (W8 ? 2 : 1) * C_::BM, BN = C_::BN;
+    constexpr int AV = BM * BK / 4 / NT, BV = BN * BK / 4 / NT;   // float4 per thread per slice
     constexpr bool HAS_MASK = MASKED;
     constexpr bool FWDLIKE = is_fwd(MODE);
     // SPLIT stage: 3 planes per operand of [row][32 bf16 + 8 pad] (80-byte rows: conflict-free b128)
@@ -461,7 +474,7 @@ conv_gemm_kernel(const GemmParams p)
     const int n0 = (tile % ntn) * BN;
 
     // ---------------- per-thread gather state -----------------------------------
-    constexpr int KC_C4 = BK / 4, KC_RPP = 256 / KC_C4;   // float4 per row, rows per pass
+    constexpr int KC_C4 = BK / 4, KC_RPP = NT / KC_C4;    // float4 per row, rows per pass
     const int kc_row = tid / KC_C4, kc_c4 = tid % KC_C4;
     constexpr int NA = AV;                              // A rows a thread addresses
     auto a_row = [&](int i) { return kc_row + KC_RPP * i; };
@@ -938,7 +951,8 @@ conv_gemm_kernel(const GemmParams p)
     };
 
     // one K slice: fragments of block kb+1 are fetched while block kb's MFMAs issue
-    auto compute = [&](int buf) {
+    auto compute_ = [&](int buf, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;   // issue the next slice's loads here
         if constexpr (SPLIT) {
             const unsigned short *pa = reinterpret_cast<const unsigned short *>(smem[buf]);
             const unsigned short *pb = pa + 3 * PLA;
@@ -961,7 +975,7 @@ conv_gemm_kernel(const GemmParams p)
             };
             frag(0, fa[0], fb[0]);
 #ifndef MRCNN_DBG_NOGLOBAL
-            issue_loads();
+            if constexpr (ISSUE) issue_loads();
 #endif
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
@@ -977,7 +991,18 @@ conv_gemm_kernel(const GemmParams p)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 fa[ks & 1][i][QA[c]], fb[ks & 1][j][QB[c]], acc[i][j], 0, 0, 0);
             }
-            if constexpr (ILV) {
+            if constexpr (ILV && !ISSUE) {
+                // (W8, waves that multiply first: their next slice's loads are issued after the store)
+                // first fragments, then one fragment read of the second K step per two MFMAs
+                constexpr int NFR = 3 * (TM + TN), NMH = 6 * TM * TN;
+                __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
+#pragma unroll
+                for (int g = 0; g < NFR; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMH * (BK / 16) - 2 * NFR, 0);
+            } else if constexpr (ILV) {
                 // issue order: first fragments, then the first K step's MFMAs with one global load
                 // and the second K step's fragment reads dealt out between them, then the rest
                 constexpr int NFR = 3 * (TM + TN), NMH = 6 * TM * TN;
@@ -1033,6 +1058,7 @@ conv_gemm_kernel(const GemmParams p)
         if (MRCNN_GEMM_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
         if (MRCNN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(2);
     };
+    auto compute = [&](int buf) { compute_(buf, std::true_type()); };
 
 #ifdef MRCNN_GEMM_CLOCKPROBE
     const unsigned probe_slot = blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y;
@@ -1044,7 +1070,39 @@ conv_gemm_kernel(const GemmParams p)
         issue_loads();
         store_slice(0);
     }
-    if (SINGLEBUF) {
+    if constexpr (W8) {
+        // (see the W8 note above the kernel) stage k & 1 holds slice k; slice k + 1 is in registers
+        // (or in flight) while slice k is multiplied
+        auto no_loads = [&]() {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) oa[i] = kOOB;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) ob[i] = kOOB;
+        };
+        if (nslices > 1) {
+            load_slice(1);
+            issue_loads();
+        }
+        __syncthreads();
+        const bool stage_first = wave >= 4;               // wave-uniform
+        for (int kt = 0; kt < nslices; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nslices;
+            if (stage_first) {
+                if (more) store_slice(cur ^ 1);
+                if (kt + 2 < nslices) load_slice(kt + 2); else no_loads();
+                compute_(cur, std::true_type());          // (issues the loads of slice k + 2)
+            } else {
+                compute_(cur, std::false_type());
+                if (more) store_slice(cur ^ 1);
+                if (kt + 2 < nslices) {
+                    load_slice(kt + 2);
+                    issue_loads();
+                }
+            }
+            __syncthreads();
+        }
+    } else if (SINGLEBUF) {
         // one LDS stage (37 KB -> three workgroups per CU, three waves per SIMD): a wave spends
         // ~40 % of a slice issuing MFMAs and ~60 % staging, so three interleaved waves are
         // needed to keep the pipe full; two barriers per slice instead of one.
@@ -1528,6 +1586,8 @@ int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal star
 int g_big_split_k = 0;  // mrcnn_set_tuning("big_split_k"): small-M problems as 128x128 tiles cut along K.
                       // 0 (default) = off (64x64 tiles), -1 = the rule in launch(), k > 0 = aim at k workgroups
 int g_stagger_min_rounds = 2;
+int g_w8 = 1;         // mrcnn_set_tuning("w8", 0/1): 256x128 tiles on 512-thread workgroups (W8) for the large
+                      // pointwise forward-form launches of the split-operand arithmetic
 
 template <int TM, int TN, int MODE, bool MASKED>
 void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_t s, int batch = 1)
@@ -1586,6 +1646,36 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
 }
 
 inline bool is_masked(const GemmParams &p) { return p.mask_y != nullptr || p.in_scale != nullptr; }
+
+// ---- W8 launches (see the note above conv_gemm_kernel) -------------------------------------------
+constexpr int kW8BM = 256, kW8BN = 128;
+
+inline bool w8_pointwise(const GemmParams &p)
+{
+    return p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.perm_n == 0 && !p.stem &&
+           p.gp == p.sh && p.gq == p.sw;
+}
+
+// a forward-form launch qualifies: split-operand arithmetic, no mask staging, plain output rows,
+// 1x1 / stride 1 gather, K >= 8 slices, at least three rounds of 256 tiles, rows that fill their tiles
+inline bool w8_ok(const GemmParams &p, int batch = 1)
+{
+    if (!g_w8 || !(g_split_bf16 & 1) || is_masked(p) || p.out_mode != OUT_PLAIN || !w8_pointwise(p) ||
+        p.split_len != 0 || p.m_lo != 0)
+        return false;
+    const int64_t tm = mrcnn::ceil_div(p.M, kW8BM), tn = mrcnn::ceil_div(p.N, kW8BN);
+    // (measured, profiles/r06b_w8_shapes.txt: the RoI head's 1x1 layers and their transposed-filter data
+    // gradients gain 4 - 7 %; the batch-2 backbone's 270 - 530-tile, 2 - 8-slice launches lose 5 - 20 %)
+    return p.N >= kW8BN && p.Kc >= 256 && tm * tn * batch >= 768 && (p.M % kW8BM == 0 || p.M >= 16 * kW8BM);
+}
+
+void launch_w8_kernel(const GemmParams &p, int64_t wgs, int batch, hipStream_t s)
+{
+    hipEvent_t ev0, ev1;
+    mrcnn::prof_take(&ev0, &ev1);
+    hipExtLaunchKernelGGL((conv_gemm_kernel<2, 2, FWD, false, false, true, true>),
+                          dim3((unsigned)wgs, 1, batch), dim3(512), g_extra_lds, s, ev0, ev1, 0, p);
+}
 
 template <int TM, int TN, int MODE>
 void launch_kernel(const GemmParams &p, int64_t tiles, int splits, hipStream_t s, int batch = 1)
@@ -1771,6 +1861,56 @@ void launch_remainder(const GemmParams &p, int rows_lo, hipStream_t s)
     launch_split_rows<MODE>(p, rows_lo, (int)splits, total_slices, s);
 }
 
+// One W8 launch for the whole problem: whole rounds of 256 tiles (one 512-thread workgroup per CU)
+// and, when the last round would be less than ~60 % full, its rows as K-split pieces appended to
+// the same grid + the ordered slab sum (the fused-tail scheme of launch_fused_tail).
+void launch_w8(GemmParams p, hipStream_t s)
+{
+    const int64_t tm = mrcnn::ceil_div(p.M, kW8BM), tn = mrcnn::ceil_div(p.N, kW8BN);
+    const int64_t T = tm * tn, full = T / 256, rem = T - full * 256;
+    const double kdepth = (double)p.Kc;
+    const double flops = 2.0 * p.M * p.N * kdepth;
+    const double bytes = 4.0 * ((double)p.M * p.N + (double)p.M * p.Kc + (double)p.N * kdepth);
+    const int total_slices = (int)mrcnn::ceil_div(p.Kc, BK);
+    int64_t main_rows_tiles = tm;
+    if (rem > 0 && rem < 154 && full >= 1 && g_fused_tail && p.split_ws && p.N % 4 == 0 && p.ldc == p.N)
+        main_rows_tiles = (full * 256) / tn;
+    const int rows_main = (int)std::min<int64_t>(p.M, main_rows_tiles * kW8BM);
+    int64_t splits = 1, tail_tiles = 0;
+    if (rows_main < p.M) {
+        const int rows_left = p.M - rows_main;
+        tail_tiles = mrcnn::ceil_div(rows_left, kW8BM) * tn;
+        splits = std::min<int64_t>(std::min<int64_t>(16, total_slices / 4), mrcnn::ceil_div(256, tail_tiles));
+        while (splits > 1 && (int64_t)rows_left * p.N * splits * 4 > kSplitWsBytes) --splits;
+    }
+    mrcnn::ProfKernelScope prof(mrcnn::PROF_CONV_FWD_128, flops, bytes);
+    if (splits < 2) {
+        p.m_lo = 0;
+        launch_w8_kernel(p, T, 1, s);
+        return;
+    }
+    const int rows_left = p.M - rows_main;
+    p.tail_split_len = (int)mrcnn::ceil_div(total_slices, splits);
+    splits = mrcnn::ceil_div(total_slices, p.tail_split_len);
+    p.tail_first = (int)(main_rows_tiles * tn);
+    p.tail_splits = (int)splits;
+    p.tail_row0 = rows_main;
+    p.tail_ws = p.split_ws;
+    p.tail_stride = (int64_t)rows_left * p.N;
+    p.tail_bytes = (unsigned)(p.tail_stride * 4);
+    p.m_lo = 0;
+    launch_w8_kernel(p, p.tail_first + tail_tiles * splits, 1, s);
+    FixParams f = {};
+    f.ws = p.split_ws; f.C = p.C;
+    f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.residual = p.residual;
+    f.res_g = p.res_g; f.res_y = p.res_y; f.out_mask_y = p.out_mask_y;
+    f.splits = (int)splits; f.rows = rows_left; f.N = p.N; f.row0 = rows_main; f.ldc = p.ldc;
+    f.flags = p.flags; f.stride = p.tail_stride;
+    f.perm_n = 0; f.pq = p.gp * p.gq;
+    const int64_t n = (int64_t)rows_left * (p.N / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)mrcnn::ceil_div(n, 256)), dim3(256), 0, s, f);
+}
+
 extern float g_wino_ambiguity;
 int g_small_whole_max = 1024, g_small_rem_max = 154;   // developer knobs (A/B)
 int g_big_min_tiles = 384;        // mrcnn_set_tuning("big_min_tiles"): fewest 128x128 tiles that get 128x128 tiles
@@ -1847,7 +1987,9 @@ int launch(const GemmParams &p0, int splits, hipStream_t s)
         }
         while (ksplits > 1 && (int64_t)p.M * p.N * ksplits * 4 > kSplitWsBytes) --ksplits;
     }
-    if (ksplits >= 2) {
+    if (MODE == FWD && splits == 1 && w8_ok(p)) {
+        launch_w8(p, s);
+    } else if (ksplits >= 2) {
         launch_split_rows<MODE, 2>(p, 0, (int)ksplits, total_slices_, s);
     } else if (!big_ok || T < g_big_min_tiles) {
         launch_small<MODE>(p, s);
@@ -2010,10 +2152,15 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
         g_big_split_k = value;
         return 0;
     }
+    if (strcmp(name, "w8") == 0) {
+        g_w8 = value;
+        return 0;
+    }
     if (strcmp(name, "stagger_min_rounds") == 0) {
         g_stagger_min_rounds = value;
         return 0;
     }
+    if (mrcnn::roi_align_set_tuning(name, value) == 0) return 0;     // roi_fwd_lanes / roi_bwd_lanes
     MRCNN_REQUIRE(false, "set_tuning: unknown option '%s'", name);
     return 1;
 }

@@ -466,7 +466,10 @@ int wino_batched_gemm(const float *a, const float *b, float *out, int64_t T, int
     const bool two_launches = big && rem > 0 && rem <= 64 && p.M >= 256;
     mrcnn::ProfKernelScope prof(big ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_FWD_64, flops, bytes,
                                 two_launches ? 2 : 1);
-    if (two_launches) {
+    if (big && w8_ok(p, kXi)) {
+        // 256 x 128 tiles on 512-thread workgroups (conv_gemm.hip, W8): the 36 problems in one grid
+        launch_w8_kernel(p, mrcnn::ceil_div(p.M, kW8BM) * mrcnn::ceil_div(p.N, kW8BN), kXi, s);
+    } else if (two_launches) {
         // a last row tile that is at most half full (the RPN's 546 tiles of a 2 x 51 x 84 map:
         // 4 x 128 + 34) runs as 64-row tiles instead of a whole 128-row tile of mostly padding
         const int full = p.M - rem;

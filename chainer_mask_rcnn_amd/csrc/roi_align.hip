@@ -11,6 +11,9 @@
 //
 // Built with -ffp-contract=off and the reference's operation order so that the
 // forward is bit-identical to the fp32 CPU restatement (oracle/roi_align_ref.c).
+#include <algorithm>
+#include <cstring>
+
 #include "common.h"
 
 namespace {
@@ -321,7 +324,10 @@ roi_align_fwd_kernel(const V *__restrict__ x, const float *__restrict__ rois, V 
     const int n = order ? order[row / OH] : row / OH;
     const RoiGeom g = roi_geom(rois + 5 * n, spatial_scale, PH, PW, sampling_ratio);
 
-    for (int c = threadIdx.x; c < CV; c += blockDim.x) {
+    // channel chunks of blockDim.x lanes: blockIdx.y, the SLOW grid index — every output row of chunk
+    // 0 is dispatched before chunk 1, so an XCD's run of rows touches its region of the map one
+    // channel chunk (0.5 - 1 KB per pixel instead of 8 KB at 2048 channels) at a time
+    for (int c = (int)(blockIdx.y * blockDim.x + threadIdx.x); c < CV; c += (int)(gridDim.y * blockDim.x)) {
         const V *__restrict__ img = x + (int64_t)g.batch * H * W * CV + c;
         V *__restrict__ out = y + ((int64_t)n * OH + oh) * OW * CV + c;
         FwdEpi<V> epi;
@@ -802,6 +808,9 @@ roi_align_bwd_owner_kernel(const V *__restrict__ gy, const int4 *__restrict__ ex
     }
 }
 
+int g_roi_fwd_lanes = 0;     // mrcnn_set_tuning("roi_fwd_lanes"): cap of the forward's lanes per workgroup (0 = 256)
+int g_roi_bwd_lanes = 0;     // mrcnn_set_tuning("roi_bwd_lanes"): same for the pixel-owner backward
+
 inline int pick_threads(int cv)
 {
     int t = ((cv + 63) / 64) * 64;
@@ -840,33 +849,43 @@ int roi_align_fwd_launch(const float *x, const float *rois, float *y, int N, int
     hipEvent_t ev0, ev1;      // kernel-only timing from the dispatch packet (bench.py roofline)
     mrcnn::prof_begin_ext(mrcnn::PROF_ROI_ALIGN_FWD, 0.,
                           4.0 * ((double)bins * C + (double)N * H * W * C), &ev0, &ev1);
-    const dim3 grid((R * OH + 7) / 8 * 8);
+    const int cvl = (C % 4 == 0) ? C / 4 : C;
+    int nthr = pick_threads(cvl);
+    if (g_roi_fwd_lanes > 0) nthr = std::min(nthr, g_roi_fwd_lanes);
+    const dim3 grid((R * OH + 7) / 8 * 8, (cvl + nthr - 1) / nthr);
     const bool vec = C % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
                      (!epi || (((uintptr_t)scale % 16 == 0) && ((uintptr_t)shift % 16 == 0)));
     if (vec) {
         const int cv = C / 4;
         if (epi)
-            hipExtLaunchKernelGGL((roi_align_fwd_kernel<float4, true>), grid, dim3(pick_threads(cv)), 0, s,
+            hipExtLaunchKernelGGL((roi_align_fwd_kernel<float4, true>), grid, dim3(nthr), 0, s,
                                   ev0, ev1, 0, (const float4 *)x, rois, (float4 *)y, H, W, cv, PH, PW,
                                   spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH, order,
                                   (const float4 *)scale, (const float4 *)shift, relu);
         else
-            hipExtLaunchKernelGGL((roi_align_fwd_kernel<float4, false>), grid, dim3(pick_threads(cv)), 0, s,
+            hipExtLaunchKernelGGL((roi_align_fwd_kernel<float4, false>), grid, dim3(nthr), 0, s,
                                   ev0, ev1, 0, (const float4 *)x, rois, (float4 *)y, H, W, cv, PH, PW,
                                   spatial_scale, sampling_ratio, OH, OW, bin_stride, R * OH, order,
                                   (const float4 *)nullptr, (const float4 *)nullptr, 0);
     } else if (epi) {
-        hipExtLaunchKernelGGL((roi_align_fwd_kernel<float, true>), grid, dim3(pick_threads(C)), 0, s, ev0,
+        hipExtLaunchKernelGGL((roi_align_fwd_kernel<float, true>), grid, dim3(nthr), 0, s, ev0,
                               ev1, 0, x, rois, y, H, W, C, PH, PW, spatial_scale, sampling_ratio, OH, OW,
                               bin_stride, R * OH, order, scale, shift, relu);
     } else {
-        hipExtLaunchKernelGGL((roi_align_fwd_kernel<float, false>), grid, dim3(pick_threads(C)), 0, s, ev0,
+        hipExtLaunchKernelGGL((roi_align_fwd_kernel<float, false>), grid, dim3(nthr), 0, s, ev0,
                               ev1, 0, x, rois, y, H, W, C, PH, PW, spatial_scale, sampling_ratio, OH, OW,
                               bin_stride, R * OH, order, (const float *)nullptr, (const float *)nullptr, 0);
     }
     return mrcnn::check_launch("roi_align_fwd");
 }
 }  // namespace
+
+int mrcnn::roi_align_set_tuning(const char *name, int value)     // behind mrcnn_set_tuning (conv_gemm.hip)
+{
+    if (strcmp(name, "roi_fwd_lanes") == 0) { g_roi_fwd_lanes = value; return 0; }
+    if (strcmp(name, "roi_bwd_lanes") == 0) { g_roi_bwd_lanes = value; return 0; }
+    return 1;
+}
 
 extern "C" int mrcnn_roi_align_fwd_ex(const float *x, const float *rois, float *y, int N, int H,
                                       int W, int C, int R, int PH, int PW, int bin_stride,
@@ -962,14 +981,15 @@ extern "C" int mrcnn_roi_align_bwd_ws(const float *gy, const float *rois, float 
         hipExtLaunchKernelGGL(roi_bwd_tables_kernel, dim3(R), dim3(256), 0, s, ev0, nullptr, 0, rois, H,
                               W, w.Wp, PH, PW, OH, OW, bin_stride, spatial_scale, sampling_ratio, ext,
                               Ay, Bx);
-        const int nthr = pick_threads(vec ? C / 4 : C);
+        int nthr = pick_threads(vec ? C / 4 : C);
+        if (g_roi_bwd_lanes > 0) nthr = std::min(nthr, g_roi_bwd_lanes);
         const dim3 grid((unsigned)((tiles + 7) / 8 * 8), (unsigned)(((vec ? C / 4 : C) + nthr - 1) / nthr));
         if (vec)
-            hipExtLaunchKernelGGL(roi_align_bwd_owner_kernel<float4>, grid, dim3(pick_threads(C / 4)),
+            hipExtLaunchKernelGGL(roi_align_bwd_owner_kernel<float4>, grid, dim3(nthr),
                                   0, s, nullptr, ev1, 0, (const float4 *)gy, ext, Ay, Bx, (float4 *)gx,
                                   R, N, H, W, w.Wp, C / 4, OH, OW);
         else
-            hipExtLaunchKernelGGL(roi_align_bwd_owner_kernel<float>, grid, dim3(pick_threads(C)), 0, s,
+            hipExtLaunchKernelGGL(roi_align_bwd_owner_kernel<float>, grid, dim3(nthr), 0, s,
                                   nullptr, ev1, 0, gy, ext, Ay, Bx, gx, R, N, H, W, w.Wp, C, OH, OW);
         return mrcnn::check_launch("roi_align_bwd");
     }
