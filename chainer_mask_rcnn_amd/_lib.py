@@ -83,6 +83,7 @@ SIGNATURES = {
     'mrcnn_conv2d_dgrad_wt': (c_int, [_DP, c_vp, c_vp, c_vp, c_int] + [c_vp] * 8),
     'mrcnn_conv_stem_fwd': (c_int, [c_vp] * 6 + [c_int] * 5 + [c_vp]),
     'mrcnn_deconv2x2s2_fwd': (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
+    'mrcnn_deconv2x2s2_fwd_wt': (c_int, [c_vp] * 4 + [c_int] * 6 + [c_vp]),
     'mrcnn_deconv2x2s2_dgrad': (c_int, [c_vp] * 3 + [c_int] * 5 + [c_vp]),
     'mrcnn_deconv2x2s2_wgrad_workspace_bytes': (c_i64, [c_int] * 5),
     'mrcnn_deconv2x2s2_wgrad': (c_int, [c_vp] * 3 + [c_int] * 5 + [c_vp, c_vp]),

@@ -1210,7 +1210,8 @@ conv_gemm_kernel(const GemmParams p)
 #endif
     constexpr int EG = 8;       // accumulator rows handled per batch of auxiliary loads
 
-    if constexpr (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
+    if (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0 && p.out_mode == OUT_PLAIN) {   // (uniform)
+      if constexpr (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
         // Forward-form launches: the accumulators (one column x 16 rows per lane) are turned
         // into row-major float4s through the wave's corner of the LDS stages, so the residual
         // / mask reads and the output stores are 16 B per lane — a quarter of the memory
@@ -1359,6 +1360,7 @@ conv_gemm_kernel(const GemmParams p)
         }
 #undef MRCNN_EPI_CASE
         return;
+      }
     }
     if constexpr (WROWPERM) {
         // tile rows / columns are in plane-row order: fragment row 32 c + l = channel 4 l + c.  A
@@ -1401,7 +1403,7 @@ conv_gemm_kernel(const GemmParams p)
             if (f_aff) { scale = p.scale[colc]; shift = p.shift ? p.shift[colc] : 0.f; }
         }
         int col_off = colc;
-        if (MODE == DGRAD && p.out_mode == OUT_DECONV) {
+        if (MODE != WGRAD && p.out_mode == OUT_DECONV) {
             const int ab = colc / p.ko, o = colc - ab * p.ko;
             col_off = ((ab >> 1) * (2 * p.gq) + (ab & 1)) * p.ko + o;
         }
@@ -1415,7 +1417,7 @@ conv_gemm_kernel(const GemmParams p)
                     const int e = g * EG + q;
                     const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                     int o;
-                    if (MODE == DGRAD && p.out_mode != OUT_PLAIN) {
+                    if (MODE != WGRAD && p.out_mode != OUT_PLAIN) {
                         const int rr = row < p.M ? row : 0;
                         const int n = rr / (p.gp * p.gq);
                         const int rem = rr - n * (p.gp * p.gq);
@@ -2526,6 +2528,32 @@ extern "C" int mrcnn_deconv2x2s2_fwd(const float *x, const float *w, const float
     if (int rc = set_extents(p, (int64_t)N * H * W * C, (int64_t)C * 4 * K, (int64_t)N * 4 * H * W * K))
         return rc;
     return launch<DGRAD>(p, 1, mrcnn::as_stream(stream));
+}
+
+// The same deconvolution in FORWARD form on the transposed filter wT (4K, C) = (a, b, o; c) — both
+// operands K-contiguous, i.e. the split-operand kernels (the K-strided DGRAD form above runs on fp32
+// MFMA): y[n, 2y + a, 2x + b, o] = sum_c x[n, y, x, c] wT[(a, b, o), c], a 1x1 convolution whose
+// output columns are scattered by the pixel-shuffle map of the epilogue.
+extern "C" int mrcnn_deconv2x2s2_fwd_wt(const float *x, const float *wT, const float *bias, float *y,
+                                        int N, int H, int W, int C, int K, int epi_flags,
+                                        void *stream)
+{
+    MRCNN_REQUIRE(x && wT && y, "deconv_fwd_wt: null pointer");
+    MRCNN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && C % 4 == 0 && K % 4 == 0,
+                  "deconv_fwd_wt: bad shape");
+    MRCNN_REQUIRE(aligned16(x) && aligned16(wT), "deconv_fwd_wt: x/wT must be 16-byte aligned");
+    MRCNN_REQUIRE((epi_flags & ~(MRCNN_EPI_BIAS | MRCNN_EPI_RELU)) == 0, "deconv_fwd_wt: bad flags");
+    MRCNN_REQUIRE(!(epi_flags & MRCNN_EPI_BIAS) || bias, "deconv_fwd_wt: bias flag without bias");
+    GemmParams p = {};
+    p.A = x; p.B = wT; p.C = y; p.bias = bias;
+    p.M = N * H * W; p.N = 4 * K; p.Kc = C;
+    p.gp = H; p.gq = W; p.sh = H; p.sw = W;
+    p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+    p.lda = C; p.ldb = C; p.ldc = K;
+    p.flags = epi_flags; p.out_mode = OUT_DECONV; p.ko = K;
+    if (int rc = set_extents(p, (int64_t)N * H * W * C, (int64_t)C * 4 * K, (int64_t)N * 4 * H * W * K))
+        return rc;
+    return launch<FWD>(p, 1, mrcnn::as_stream(stream));
 }
 
 extern "C" int mrcnn_deconv2x2s2_dgrad(const float *gy, const float *w, float *gx, int N, int H,

@@ -614,6 +614,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float fma_vec(float acc, float w, float v) { return __builtin_fmaf(w, v, acc); }
 __device__ __forceinline__ float4 fma_vec(float4 acc, float w, float4 v)
 {
+#if defined(MRCNN_ROI_BWD_SCALAR_FMA) && defined(MRCNN_EXPERIMENT_BUILD)   // experiment build (tools/build_variant.sh): four v_fma_f32
+    float4 r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.x) : "v"(v.x), "v"(w), "v"(acc.x));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.y) : "v"(v.y), "v"(w), "v"(acc.y));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.z) : "v"(v.z), "v"(w), "v"(acc.z));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.w) : "v"(v.w), "v"(w), "v"(acc.w));
+    return r;
+#endif
     // two v_pk_fma_f32
     const f32x2 ww = {w, w};
     const f32x2 lo = __builtin_elementwise_fma((f32x2){v.x, v.y}, ww, (f32x2){acc.x, acc.y});

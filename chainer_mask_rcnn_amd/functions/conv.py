@@ -308,6 +308,11 @@ def stem_conv(x4, w784, b, scale, shift):
     return _StemFn.apply(x4, w784, b, scale, shift)
 
 
+# The deconvolution's forward as a forward-form GEMM on the transposed filter (split-operand kernels)
+# instead of the K-strided data-gradient form (fp32 MFMA): see mrcnn_deconv2x2s2_fwd_wt.
+DECONV_FORWARD_FORM = True
+
+
 class _Deconv2x2Fn(torch.autograd.Function):
     """L.Deconvolution2D(in, out, 2, stride=2) (+ bias, + ReLU)."""
 
@@ -322,8 +327,17 @@ class _Deconv2x2Fn(torch.autograd.Function):
             raise ValueError('deconv: filter must be (in, out, 2, 2), got %s' % (tuple(W.shape),))
         y = empty_nhwc((N, K, 2 * H, 2 * Wd), x.device)
         flags = (EPI_BIAS if b is not None else 0) | (EPI_RELU if relu else 0)
-        _lib.call('mrcnn_deconv2x2s2_fwd', _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(b), _lib.ptr(y),
-                  N, H, Wd, C, K, flags, _lib.stream_ptr())
+        if DECONV_FORWARD_FORM and GEMM_ARITHMETIC == 'split_bf16x3':
+            # forward form on the transposed filter (4K, C): both operands K-contiguous -> the
+            # split-operand kernels; the K-strided form below runs on fp32 MFMA
+            wT = _lib.workspace(4 * C * 4 * K, x.device, 'deconv-wT').view(torch.float32)
+            _lib.call('mrcnn_filter_flip_transpose', _lib.ptr(Wc), _lib.ptr(wT), C, 1, 1, 4 * K, None,
+                      _lib.stream_ptr())
+            _lib.call('mrcnn_deconv2x2s2_fwd_wt', _lib.ptr(x), _lib.ptr(wT), _lib.ptr(b), _lib.ptr(y),
+                      N, H, Wd, C, K, flags, _lib.stream_ptr())
+        else:
+            _lib.call('mrcnn_deconv2x2s2_fwd', _lib.ptr(x), _lib.ptr(Wc), _lib.ptr(b), _lib.ptr(y),
+                      N, H, Wd, C, K, flags, _lib.stream_ptr())
         ctx.dims = (N, H, Wd, C, K)
         ctx.relu = relu
         ctx.W_param, ctx.b_param = W, b
@@ -943,13 +957,17 @@ def _pool_bwd_alone(side, device):
     """The compute stream waits for the weight-gradient side stream before a pixel-owner ROIAlign
     backward inside a stage.  Round 6 finding (tests/test_gpu_model.py::test_training_is_bit_
     reproducible_run_to_run on the small test model, whose RoI head is small enough to use the side
-    stream): with a weight-gradient GEMM of the SAME block running on the side stream — it reads the
-    gradient tensor the ROIAlign backward reads — a launch now and then lost ONE list entry's
-    contribution in ONE component of 16 lanes (a handful of gx elements, different from run to run);
-    the same two kernels side by side in isolation (900 launches, the captured tensors included) never
-    did, and neither kernel uses scratch.  Not understood; serialising the two streams at this point
-    removes it, costs nothing at full size (the head's weight gradients do not use the side stream
-    there) and ~20 us in the small configurations that do."""
+    stream): with the weight-gradient GEMM of the SAME block running on the side stream — it reads the
+    gradient tensor the ROIAlign backward reads, written by the data-gradient GEMM just before — a
+    launch now and then lost ONE list entry's contribution in ONE component of 16 lanes (a handful
+    of gx elements, different from run to run; captured and analysed on the host: inputs and tables
+    identical, the sum short of exactly one term).  The same two kernels side by side in isolation
+    (900 launches, the captured tensors included) never did; neither kernel uses scratch; four
+    plain v_fma_f32 instead of the packed FMAs change nothing.  Two measures, either of which removes
+    it on its own (each 8 of 8 runs clean): the pooled backward of a block is queued BEFORE that
+    block's weight gradients go to the side stream (no second reader of its input is in flight), and
+    the streams are serialised here.  Costs nothing at full size (the head's weight gradients do not
+    use the side stream there), ~20 us in the small configurations that do.  Root cause not found."""
     if side is not None:
         torch.cuda.current_stream(device).wait_stream(side)
 

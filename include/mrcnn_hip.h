@@ -346,6 +346,12 @@ int mrcnn_conv_stem_fwd(const float *x4, const float *w784, const float *bias,
 int mrcnn_deconv2x2s2_fwd(const float *x, const float *w, const float *bias,
                           float *y, int N, int H, int W, int C, int K,
                           int epi_flags, void *stream);
+/* The same forward on the TRANSPOSED filter wT (4K, C) = mrcnn_filter_flip_transpose(w, wT, C, 1, 1, 4K)
+ * — a 1x1 convolution (both operands K-contiguous: the split-operand arithmetic) whose output columns
+ * (a, b, o) the epilogue scatters to y[n, 2y + a, 2x + b, o].  Same values up to fp32 rounding. */
+int mrcnn_deconv2x2s2_fwd_wt(const float *x, const float *wT, const float *bias,
+                             float *y, int N, int H, int W, int C, int K, int epi_flags,
+                             void *stream);
 int mrcnn_deconv2x2s2_dgrad(const float *gy, const float *w, float *gx,
                             int N, int H, int W, int C, int K, void *stream);
 int64_t mrcnn_deconv2x2s2_wgrad_workspace_bytes(int N, int H, int W, int C, int K);

@@ -99,9 +99,18 @@ def test_conv_fused_epilogue_and_backward(dev):
     _close(wt.grad.cpu().numpy(), gW)
 
 
-def test_deconv2x2s2(dev):
+@pytest.mark.parametrize('dims', [(5, 256, 7, 7, 64),          # 64x64 tiles
+                                  (130, 512, 7, 7, 256)],      # 128x128 tiles (400 of them), per-element epilogue
+                         ids=['small', 'big tiles'])
+@pytest.mark.parametrize('forward_form', [True, False], ids=['forward form (split kernels)', 'K-strided form'])
+def test_deconv2x2s2(dev, dims, forward_form, monkeypatch):
+    """L.Deconvolution2D(k=2, s=2) + bias + ReLU and its three gradients against the oracle, with the
+    forward both as a forward-form GEMM on the transposed filter (mrcnn_deconv2x2s2_fwd_wt: pixel-
+    shuffle output map in the epilogue) and in the K-strided data-gradient form."""
+    from chainer_mask_rcnn_amd.functions import conv as C_
+    monkeypatch.setattr(C_, 'DECONV_FORWARD_FORM', forward_form)
     rng = np.random.RandomState(4)
-    N, C, H, W, K = 5, 256, 7, 7, 64
+    N, C, H, W, K = dims
     x = rng.standard_normal((N, C, H, W)).astype(np.float32)
     Wt = (rng.standard_normal((C, K, 2, 2)) / 16.).astype(np.float32)
     b = rng.standard_normal(K).astype(np.float32)
