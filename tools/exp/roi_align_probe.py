@@ -9,6 +9,9 @@ import bench
 import chainer_mask_rcnn_amd as cmr
 import importlib
 ra = importlib.import_module('chainer_mask_rcnn_amd.functions.roi_align_2d')
+# this probe watches the stand-alone ROIAlign node (1024-channel map, reference order); the projected
+# head pools inside its stage node: tools/exp/roi_proj_probe.py times that arrangement
+importlib.import_module('chainer_mask_rcnn_amd.functions.conv').PROJECTED_POOLING = False
 
 
 def main():

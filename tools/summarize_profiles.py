@@ -1,13 +1,15 @@
 """Copy the judged summaries of a gpurun profile collection into profiles/ (tracked)."""
 import collections, csv, json, os, shutil, sys
 tag = sys.argv[1]
+pmc_only = '--pmc-only' in sys.argv     # (on the GPU box, before the bench lines that cite the summary)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g, p = os.path.join(root, 'gpurun_out'), os.path.join(root, 'profiles')
 os.makedirs(p, exist_ok=True)
-shutil.copy(os.path.join(g, '%s_stats' % tag, '%s_kernel_stats.csv' % tag),
-            os.path.join(p, '%s_kernel_stats.csv' % tag))
-for name in ('bench', 'bench_allkinds', 'bench_infer', 'bench_dp1', 'bench_r101', 'bench_fp32_allkinds',
-             'bench_fp32_r101'):
+if not pmc_only:
+    shutil.copy(os.path.join(g, '%s_stats' % tag, '%s_kernel_stats.csv' % tag),
+                os.path.join(p, '%s_kernel_stats.csv' % tag))
+for name in (() if pmc_only else ('bench', 'bench_allkinds', 'bench_infer', 'bench_dp1', 'bench_r101', 'bench_fp32_allkinds',
+             'bench_fp32_r101')):
     src = os.path.join(g, '%s_%s.json' % (tag, name))
     if os.path.exists(src):
         lines = [l for l in open(src).read().splitlines() if l.startswith('{')]
@@ -24,7 +26,7 @@ def agg(path, cname):
 
 
 src = os.path.join(g, '%s_fp32_stats' % tag, '%s_fp32_kernel_stats.csv' % tag)
-if os.path.exists(src):
+if os.path.exists(src) and not pmc_only:
     shutil.copy(src, os.path.join(p, '%s_fp32_kernel_stats.csv' % tag))
 f = agg(os.path.join(g, '%s_fetch' % tag, '%s_counter_collection.csv' % tag), 'FETCH_SIZE')
 w = agg(os.path.join(g, '%s_write' % tag, '%s_counter_collection.csv' % tag), 'WRITE_SIZE')
