@@ -81,8 +81,14 @@ class ResNetRoIHead(torch.nn.Module):
         for; ``roi_masks`` then has ``len(mask_rows)`` rows.  ``None`` = all rows."""
         from .. import optimizers
         optimizers.join_pending_all()      # deferred updates of the head's parameters (if any)
-        roi_indices = roi_indices.to(torch.float32)
-        indices_and_rois = torch.cat((roi_indices[:, None], rois), dim=1)
+        # (batch, x1, y1, x2, y2) rows when the caller built them with the RoIs (MaskRCNNTrainChain)
+        rois5 = getattr(rois, '_mrcnn_rois5', None)
+        if rois5 is not None and tuple(rois5.shape) != (rois.shape[0], 5):
+            rois5 = None
+        indices_and_rois = None
+        if rois5 is None:
+            roi_indices = roi_indices.to(torch.float32)
+            indices_and_rois = torch.cat((roi_indices[:, None], rois), dim=1)
         res5_stride = self.roi_size // 7
         # Both consumers of res5 wanted and the mask branch on a row subset (training): the fused
         # stage hands back (pool5, res5[mask_rows]) and combines their gradients in one pass
@@ -91,8 +97,11 @@ class ResNetRoIHead(torch.nn.Module):
         kw = dict(tail_rows=mask_rows) if fused_tail else {}
         from ..functions import conv as _conv
         projected = self.projected_pooling if self.projected_pooling is not None else _conv.PROJECTED_POOLING
-        if projected and self.pooling_func is functions.roi_align_2d and \
-                getattr(self.res5, 'fused_stage', False) and rois.shape[0] > 0:
+        projected = projected and self.pooling_func is functions.roi_align_2d and \
+            getattr(self.res5, 'fused_stage', False) and rois.shape[0] > 0
+        if not projected and indices_and_rois is None:
+            indices_and_rois = rois5[:, [0, 2, 1, 4, 3]]      # the reference-order branches take 'yx' rows
+        if projected:
             # the stage node pools inside block a: conv1 / conv4 (1x1, stride s) read only the bins
             # (s*i, s*j) of the pooled map, and they commute with ROIAlign
             order = getattr(rois, '_mrcnn_order', None)
@@ -101,7 +110,8 @@ class ResNetRoIHead(torch.nn.Module):
             pre = None
             if not (torch.is_grad_enabled() and (x.requires_grad or self.res5.a.conv1.W.requires_grad)):
                 pre = _conv.projected_map(x, self.res5.a.conv1.W, self.res5.a.conv4.W)
-            spec = _conv.RoiSpec(indices_and_rois[:, [0, 2, 1, 4, 3]], self.roi_size, self.roi_size,
+            spec = _conv.RoiSpec(rois5 if rois5 is not None else indices_and_rois[:, [0, 2, 1, 4, 3]],
+                                 self.roi_size, self.roi_size,
                                  self.spatial_scale, bin_stride=res5_stride, order=order, proj=pre)
             res5 = self.res5(x, first_stride=1, roi=spec, **kw)
         elif res5_stride > 1 and self.pooling_func is functions.roi_align_2d:

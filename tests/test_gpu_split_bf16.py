@@ -112,8 +112,10 @@ def test_split_k_tails(dev, split, case):
         TC.test_small_m_split_k_leftover_rows(dev, case, big_split_k)
 
 
-def test_deconv_and_linear(dev, split):
-    TC.test_deconv2x2s2(dev)
+@pytest.mark.parametrize('forward_form', [True, False])
+def test_deconv_and_linear(dev, split, forward_form, monkeypatch):
+    for dims in ((5, 256, 7, 7, 64), (130, 512, 7, 7, 256)):
+        TC.test_deconv2x2s2(dev, dims, forward_form, monkeypatch)
     TC.test_linear(dev)
 
 

@@ -1,7 +1,7 @@
 # usage (GPU box): bash tools/exp/round_r06.sh <tag>  -> gpu tests, smoke, the round's profile collection (PMC passes
 # BEFORE the bench lines that cite them: tools/collect_round_profiles.sh), probes and same-box A/Bs of round 6
 TAG=${1:-r06b}
-set -x
+# (no shell trace: the A/B files are read as they are)
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -q -m gpu > gpurun_out/${TAG}_gputests.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_gputests.log | tail -2
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1; tail -2 gpurun_out/${TAG}_smoke.log
@@ -29,3 +29,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_infer_stats -o ${TAG}_infer -- python $GRAFT_REPO_ROOT/bench.py --workload infer --steps 4 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_infer_stats.log 2>&1
 cd $GRAFT_REPO_ROOT
 ls gpurun_out | grep ${TAG} | head -60
+python tools/exp/train_curve.py > gpurun_out/${TAG}_train_curve.txt 2>&1
