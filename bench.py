@@ -332,14 +332,15 @@ def pmc_traffic(kernel_name, split=False):
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_fetch_write.json')))
     if not files:
         return None
-    m = re.match(r'conv_gemm_kernel<(\d),(\d),(\w+)>', kernel_name)
+    m = re.match(r'conv_gemm_kernel<(\d),(\d),(\w+?)(,W8)?>', kernel_name)
     if not m:
         return None
     mode = {'FWD': 0, 'DGRAD': 1, 'WGRAD': 2}[m.group(3)]
-    # profiler kinds follow the kernel symbols; the unmasked variant (<.., false, false, SPLIT..>)
+    # profiler kinds follow the kernel symbols; the unmasked variant (<.., false, false, SPLIT, W8>)
     # is what the train step runs
-    key = 'conv_gemm_kernel<%s, %s, %d, false, false, %s' % (m.group(1), m.group(2), mode,
-                                                             'true' if split else 'false')
+    key = 'conv_gemm_kernel<%s, %s, %d, false, false, %s, %s>' % (
+        m.group(1), m.group(2), mode, 'true' if split or m.group(4) else 'false',
+        'true' if m.group(4) else 'false')
     for path in reversed(files):          # newest summary that holds this symbol
         with open(path) as f:
             data = json.load(f)
@@ -385,7 +386,7 @@ def cpu_baseline():
     for k, v in tm.items():
         phases[k] = round(v - prev, 2)
         prev = v
-    return dict(value=1.0 / dt, unit='images/sec', cores=threads, kind='port',
+    return dict(value=1.0 / dt, unit='images/sec', cores=threads, kind='port', n=1,
                 seconds_per_iteration=round(dt, 2),
                 sample=('measured C1: BASELINE configs[0] in full — 1 x 800x1333 image, %d sampled '
                         'RoIs, forward + backward through oracle/np_step.py (NumPy im2col + BLAS on '

@@ -47,6 +47,7 @@ enum ProfKind {
     PROF_CONV_FWD_128 = 0, PROF_CONV_FWD_64, PROF_CONV_DGRAD_128, PROF_CONV_DGRAD_64,
     PROF_CONV_WGRAD_128, PROF_CONV_WGRAD_64, PROF_ROI_ALIGN_FWD, PROF_ROI_ALIGN_BWD,
     PROF_NMS_MASK, PROF_NMS_SCAN, PROF_TOPK, PROF_SGD, PROF_ELEMENTWISE, PROF_WINO_TRANSFORM,
+    PROF_CONV_FWD_W8,        // conv_gemm_kernel<2,2,FWD,...,W8>: 256x128 tiles on 512-thread workgroups
     PROF_NUM_KINDS
 };
 bool prof_enabled(int kind);

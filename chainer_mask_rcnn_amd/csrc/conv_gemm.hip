@@ -1885,7 +1885,7 @@ void launch_w8(GemmParams p, hipStream_t s)
         splits = std::min<int64_t>(std::min<int64_t>(16, total_slices / 4), mrcnn::ceil_div(256, tail_tiles));
         while (splits > 1 && (int64_t)rows_left * p.N * splits * 4 > kSplitWsBytes) --splits;
     }
-    mrcnn::ProfKernelScope prof(mrcnn::PROF_CONV_FWD_128, flops, bytes);
+    mrcnn::ProfKernelScope prof(mrcnn::PROF_CONV_FWD_W8, flops, bytes);
     if (splits < 2) {
         p.m_lo = 0;
         launch_w8_kernel(p, T, 1, s);

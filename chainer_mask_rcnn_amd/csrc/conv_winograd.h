@@ -464,9 +464,10 @@ int wino_batched_gemm(const float *a, const float *b, float *out, int64_t T, int
     const double bytes = 4.0 * kXi * ((double)T * N + (double)T * Kc + (double)N * Kc);
     const int rem = p.M % 128;
     const bool two_launches = big && rem > 0 && rem <= 64 && p.M >= 256;
-    mrcnn::ProfKernelScope prof(big ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_FWD_64, flops, bytes,
-                                two_launches ? 2 : 1);
-    if (big && w8_ok(p, kXi)) {
+    const bool w8 = big && w8_ok(p, kXi);
+    mrcnn::ProfKernelScope prof(w8 ? mrcnn::PROF_CONV_FWD_W8 : big ? mrcnn::PROF_CONV_FWD_128 : mrcnn::PROF_CONV_FWD_64,
+                                flops, bytes, two_launches && !w8 ? 2 : 1);
+    if (w8) {
         // 256 x 128 tiles on 512-thread workgroups (conv_gemm.hip, W8): the 36 problems in one grid
         launch_w8_kernel(p, mrcnn::ceil_div(p.M, kW8BM) * mrcnn::ceil_div(p.N, kW8BN), kXi, s);
     } else if (two_launches) {

@@ -41,11 +41,11 @@ hipEvent_t get_event()
 bool prof_timed(int kind)
 {
     if (g_prof_mode == 1) return true;
-    // mode 2: the forward-form 128x128 GEMM — the dominant kernel symbol of both workloads (half
+    // mode 2: the forward-form 128x128 GEMM and its 256x128 / 512-thread form (W8) — together half
     // of the GPU time, profiles/*_kernel_stats.csv) — and the two ROIAlign launches of a step
     // (HBM-bound kernels the north star asks a GB/s figure for; two event pairs per step)
-    return g_prof_mode == 2 && (kind == PROF_CONV_FWD_128 || kind == PROF_ROI_ALIGN_FWD ||
-                                kind == PROF_ROI_ALIGN_BWD);
+    return g_prof_mode == 2 && (kind == PROF_CONV_FWD_128 || kind == PROF_CONV_FWD_W8 ||
+                                kind == PROF_ROI_ALIGN_FWD || kind == PROF_ROI_ALIGN_BWD);
 }
 bool prof_enabled(int) { return g_prof_mode != 0; }
 
@@ -96,7 +96,8 @@ static const char *kProfNames[mrcnn::PROF_NUM_KINDS] = {
     "conv_gemm_kernel<2,2,FWD>", "conv_gemm_kernel<1,1,FWD>", "conv_gemm_kernel<2,2,DGRAD>",
     "conv_gemm_kernel<1,1,DGRAD>", "conv_gemm_kernel<2,2,WGRAD>", "conv_gemm_kernel<1,1,WGRAD>",
     "roi_align_fwd_kernel", "roi_align_bwd_kernel", "nms_mask_kernel", "nms_scan_kernel",
-    "topk_rank_kernel", "sgd_kernel", "elementwise", "wino_transform_kernels"};
+    "topk_rank_kernel", "sgd_kernel", "elementwise", "wino_transform_kernels",
+    "conv_gemm_kernel<2,2,FWD,W8>"};
 
 extern "C" int mrcnn_profile_enable(int on)
 {
