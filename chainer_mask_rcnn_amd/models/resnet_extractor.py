@@ -212,7 +212,7 @@ class ResNetExtractorBase(torch.nn.Module):
         # the stream the deferred weight gradients use (idle between two proposal windows), NOT a
         # stream of its own: a fifth stream changes which HIP streams share a hardware queue
         # (GPU_MAX_HW_QUEUES = 4) and the proposal chain then queues behind the deferred weight
-        # gradients — measured +2.4 ms under data parallelism, +6 ms with 5..8 queues
+        # gradients — measured +2.4 ms under data parallelism, +6 ms with 5..8 queues (profiles/HISTORY.md 7a)
         from ..functions.conv import defer_stream, no_filter_cache
         side, main = defer_stream(dev), torch.cuda.current_stream(dev)
         side.wait_stream(main)
