@@ -142,6 +142,7 @@ struct GemmParams {
     int flags;
     int out_mode;
     int oh, ow, ko;      // OUT_STRIDED: gx spatial dims; OUT_DECONV: ko = out channels
+    int ostride;         // OUT_STRIDED: stride of the OUTPUT rows (0: `stride`; the forward-form strided dgrad gathers densely)
     int stem;            // FWD: stem gather (8 pixels x 4 ch per K slice)
     int split_len;       // WGRAD: pixels per split; FWD/DGRAD: K slices per split (0: no split)
     int64_t split_stride;// floats between split slabs
@@ -1423,7 +1424,8 @@ conv_gemm_kernel(const GemmParams p)
                         const int rem = rr - n * (p.gp * p.gq);
                         const int gy = rem / p.gq, gx = rem - gy * p.gq;
                         if (p.out_mode == OUT_STRIDED)
-                            o = ((n * p.oh + gy * p.stride) * p.ow + gx * p.stride) * p.ldc + col_off;
+                            o = ((n * p.oh + gy * (p.ostride ? p.ostride : p.stride)) * p.ow +
+                                 gx * (p.ostride ? p.ostride : p.stride)) * p.ldc + col_off;
                         else
                             o = ((n * (2 * p.gp) + 2 * gy) * (2 * p.gq) + 2 * gx) * p.ko + col_off;
                     } else if (FWDLIKE && p.perm_n > 0 && !slab_rows) {
@@ -1588,6 +1590,7 @@ int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal star
 int g_big_split_k = 0;  // mrcnn_set_tuning("big_split_k"): small-M problems as 128x128 tiles cut along K.
                       // 0 (default) = off (64x64 tiles), -1 = the rule in launch(), k > 0 = aim at k workgroups
 int g_stagger_min_rounds = 2;
+int g_w8_min_k = 256; // mrcnn_set_tuning("w8_min_k"): shallowest K (input channels) a W8 launch takes
 int g_w8 = 1;         // mrcnn_set_tuning("w8", 0/1): 256x128 tiles on 512-thread workgroups (W8) for the large
                       // pointwise forward-form launches of the split-operand arithmetic
 
@@ -1668,7 +1671,7 @@ inline bool w8_ok(const GemmParams &p, int batch = 1)
     const int64_t tm = mrcnn::ceil_div(p.M, kW8BM), tn = mrcnn::ceil_div(p.N, kW8BN);
     // (measured, profiles/r06b_w8_shapes.txt: the RoI head's 1x1 layers and their transposed-filter data
     // gradients gain 4 - 7 %; the batch-2 backbone's 270 - 530-tile, 2 - 8-slice launches lose 5 - 20 %)
-    return p.N >= kW8BN && p.Kc >= 256 && tm * tn * batch >= 768 && (p.M % kW8BM == 0 || p.M >= 16 * kW8BM);
+    return p.N >= kW8BN && p.Kc >= g_w8_min_k && tm * tn * batch >= 768 && (p.M % kW8BM == 0 || p.M >= 16 * kW8BM);
 }
 
 void launch_w8_kernel(const GemmParams &p, int64_t wgs, int batch, hipStream_t s)
@@ -1917,6 +1920,7 @@ extern float g_wino_ambiguity;
 int g_small_whole_max = 1024, g_small_rem_max = 154;   // developer knobs (A/B)
 int g_big_min_tiles = 384;        // mrcnn_set_tuning("big_min_tiles"): fewest 128x128 tiles that get 128x128 tiles
 int g_small_m_split = 0;          // mrcnn_set_tuning("small_m_split", target workgroups per CU)
+int g_tiny_split = 1;             // mrcnn_set_tuning("tiny_split", 0/1): K-split of launches with <= 128 tiles and >= 32 slices
 
 template <int MODE>
 void launch_small(const GemmParams &p, hipStream_t s)
@@ -1929,6 +1933,17 @@ void launch_small(const GemmParams &p, hipStream_t s)
     // A small-M problem has only T / 256 workgroups per CU; cutting every tile along K into
     // `splits` slabs multiplies the resident waves (each at least 8 slices deep) at the price
     // of the ordered slab sum.
+    // Tiny launches that are K-deep (the head's fused cls_loc / score layer: 1024 x 408 x 2048 = 112
+    // tiles of 64 slices each on 112 of 256 CUs, 80 us of pure K-loop latency): cut along K so that
+    // ~512 workgroups share the walk, ordered slab sum as for the leftover rows.
+    if (g_tiny_split && can_split_rows<MODE>(p) && T <= 128 && total_slices >= 32) {
+        int64_t splits = std::min<int64_t>(std::min<int64_t>(16, total_slices / 8), mrcnn::ceil_div(512, T));
+        while (splits > 1 && (int64_t)p.M * p.N * splits * 4 > kSplitWsBytes) --splits;
+        if (splits >= 2) {
+            launch_split_rows<MODE>(p, 0, (int)splits, total_slices, s);
+            return;
+        }
+    }
     if (g_small_m_split > 0 && can_split_rows<MODE>(p) && T < 256ll * g_small_m_split &&
         total_slices >= 16) {
         int64_t splits = std::min<int64_t>(std::min<int64_t>(16, total_slices / 8),
@@ -2156,6 +2171,14 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "w8") == 0) {
         g_w8 = value;
+        return 0;
+    }
+    if (strcmp(name, "w8_min_k") == 0) {
+        g_w8_min_k = value;
+        return 0;
+    }
+    if (strcmp(name, "tiny_split") == 0) {
+        g_tiny_split = value;
         return 0;
     }
     if (strcmp(name, "stagger_min_rounds") == 0) {
@@ -2394,7 +2417,33 @@ extern "C" int mrcnn_conv2d_dgrad_wt(const mrcnn_conv_desc *d, const float *gy, 
                                      const float *out_scale, void *split_ws, void *stream)
 {
     if (int rc = check_desc(d)) return rc;
-    MRCNN_REQUIRE(d->stride == 1, "conv2d_dgrad_wt: stride must be 1");
+    if (d->stride > 1) {
+        // 1x1 / pad 0 strided convolution: every output pixel of the convolution sends its gradient
+        // to ONE input pixel — the same forward-form GEMM on the transposed filter, its rows
+        // scattered to the strided positions of a zero-filled gx (OUT_STRIDED in the per-element epilogue)
+        MRCNN_REQUIRE(d->R == 1 && d->S == 1 && d->pad == 0,
+                      "conv2d_dgrad_wt: stride > 1 is implemented for 1x1 / pad 0 filters");
+        MRCNN_REQUIRE(gy && wT && gx, "conv2d_dgrad_wt: null pointer");
+        MRCNN_REQUIRE(aligned16(gy) && aligned16(wT), "conv2d_dgrad_wt: gy/wT must be 16-byte aligned");
+        MRCNN_REQUIRE((epi_flags & ~MRCNN_EPI_ACCUM) == 0, "conv2d_dgrad_wt: only MRCNN_EPI_ACCUM is valid");
+        MRCNN_REQUIRE(!res_g && !res_y && !out_mask_y, "conv2d_dgrad_wt: residual gradient / output mask need stride 1");
+        hipStream_t s = mrcnn::as_stream(stream);
+        GemmParams p = {};
+        p.A = gy; p.B = wT; p.C = gx;
+        p.mask_y = mask_y; p.in_scale = in_scale; p.scale = out_scale;
+        p.M = d->N * d->P * d->Q; p.N = d->C; p.Kc = d->K;
+        p.gp = d->P; p.gq = d->Q; p.sh = d->P; p.sw = d->Q;
+        p.R = 1; p.S = 1; p.stride = 1; p.pad = 0; p.ostride = d->stride;
+        p.lda = d->K; p.ldb = d->K; p.ldc = d->C;
+        p.flags = epi_flags | (out_scale ? MRCNN_EPI_AFFINE : 0);
+        p.out_mode = OUT_STRIDED; p.oh = d->H; p.ow = d->W;
+        if (int rc = set_extents(p, (int64_t)d->N * d->P * d->Q * d->K, (int64_t)d->K * d->C,
+                                 (int64_t)d->N * d->H * d->W * d->C))
+            return rc;
+        if (!(epi_flags & MRCNN_EPI_ACCUM))
+            MRCNN_HIP_TRY(hipMemsetAsync(gx, 0, sizeof(float) * (size_t)d->N * d->H * d->W * d->C, s));
+        return launch<FWD>(p, 1, s);
+    }
     MRCNN_REQUIRE(gy && wT && gx, "conv2d_dgrad_wt: null pointer");
     MRCNN_REQUIRE(aligned16(gy) && aligned16(wT), "conv2d_dgrad_wt: gy/wT must be 16-byte aligned");
     MRCNN_REQUIRE((epi_flags & ~MRCNN_EPI_ACCUM) == 0, "conv2d_dgrad_wt: only MRCNN_EPI_ACCUM is valid");

@@ -456,8 +456,18 @@ def _stage_transposes(blocks, scales, device):
     return out
 
 
+# Strided 1x1 / pad 0 data gradients (res3.a / res4.a conv1 and conv4) in forward form on the
+# transposed filter as well: dense gather of gy, rows scattered to the strided pixels of a zero-filled
+# gx (split-operand kernels; the K-strided form runs on fp32 MFMA).
+STRIDED_DGRAD_FORWARD_FORM = True
+
+
 def _uses_transposed_dgrad(d):
-    return USE_TRANSPOSED_DGRAD and d.stride == 1 and d.R == d.S
+    if not USE_TRANSPOSED_DGRAD:
+        return False
+    if d.stride == 1:
+        return d.R == d.S
+    return STRIDED_DGRAD_FORWARD_FORM and d.R == 1 and d.S == 1 and d.pad == 0
 
 
 def _dgrad_raw(d, g, Wc, mask_y, in_scale, res_g=None, res_y=None, out=None, accum=False,
@@ -1204,8 +1214,9 @@ class _StageFn(torch.autograd.Function):
                 gm = _dgrad_raw(d4, gm, nhwc(W4), None, None, fold_scale=s4, out=gx, accum=True,
                                 out_mask_y=xm, wT=wT.get('4'))
             else:
-                gx = _dgrad_raw(d1, gh1, nhwc(W1), None, None)
-                gm = _dgrad_raw(d4, gm, nhwc(W4), None, None, fold_scale=s4, out=gx, accum=True)
+                gx = _dgrad_raw(d1, gh1, nhwc(W1), None, None, wT=wT.get('1'))
+                gm = _dgrad_raw(d4, gm, nhwc(W4), None, None, fold_scale=s4, out=gx, accum=True,
+                                wT=wT.get('4'))
                 if xm is not None:
                     gm = epilogue_bwd(gm, xm, None)
         if ng[0]:

@@ -319,7 +319,10 @@ int mrcnn_conv3x3_wino_wgrad(const mrcnn_conv_desc *d, const float *x, const flo
  * filter wT[c][R-1-r][S-1-s][k] = w[k][r][s][c] * row_scale[k] (both GEMM operands
  * K-contiguous).  mrcnn_filter_flip_transpose builds wT (C,R,S,K) from w (K,R,S,C)
  * (row_scale (K) or NULL); it moves R*S*K*C*8 bytes, negligible next to the dgrad.
- * Same extra arguments as _ex. */
+ * Same extra arguments as _ex.  Round 6: mrcnn_conv2d_dgrad_wt also takes stride > 1 for 1x1 / pad 0
+ * filters (the strided projections of res3.a / res4.a): gy is gathered densely, the rows are
+ * scattered to the strided pixels of gx, which the call zero-fills unless MRCNN_EPI_ACCUM is set
+ * (residual gradient / output mask arguments must be NULL there). */
 int mrcnn_filter_flip_transpose(const float *w, float *wT, int K, int R, int S, int C,
                                 const float *row_scale, void *stream);
 /* The same for n filters in one launch (host arrays of n device pointers / sizes; row_scale
