@@ -81,6 +81,11 @@ class ResNetRoIHead(torch.nn.Module):
         for; ``roi_masks`` then has ``len(mask_rows)`` rows.  ``None`` = all rows."""
         from .. import optimizers
         optimizers.join_pending_all()      # deferred updates of the head's parameters (if any)
+        if rois.shape[0] == 0:
+            # nothing to pool (an image without proposals): empty outputs of the right widths
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=x.device)
+            return (z(0, 4 * self.n_class) if pred_bbox else None, z(0, self.n_class) if pred_bbox else None,
+                    z(0, self.n_class - 1, self.mask_size, self.mask_size) if pred_mask else None)
         # (batch, x1, y1, x2, y2) rows when the caller built them with the RoIs (MaskRCNNTrainChain)
         rois5 = getattr(rois, '_mrcnn_rois5', None)
         if rois5 is not None and tuple(rois5.shape) != (rois.shape[0], 5):

@@ -211,12 +211,14 @@ def test_projected_block_against_float64_given_the_decisions(dev):
         assert scale_tol(getattr(a, k.split('.')[0]).W.grad.cpu().numpy(), prm[k].grad.numpy()), k
 
 
-def test_head_switch_gives_the_same_predictions(dev):
+@pytest.mark.parametrize('roi_size', [14, 7], ids=['roi_size 14 (res5 stride 2: every second bin)',
+                                                   'roi_size 7 (the class default: res5 stride 1, every bin)'])
+def test_head_switch_gives_the_same_predictions(dev, roi_size):
     """ResNetRoIHead with and without projected pooling: class scores, box regressions and mask
     logits agree to 1e-4 of their scale (inference path, no graph)."""
     import chainer_mask_rcnn_amd as cmr
     torch.manual_seed(0)
-    head = cmr.models.mask_rcnn_resnet.ResNetRoIHead(50, 5, 14, 1 / 16.).to(dev)
+    head = cmr.models.mask_rcnn_resnet.ResNetRoIHead(50, 5, roi_size, 1 / 16.).to(dev)
     x = torch.randn((2, 1024, 13, 17), device=dev)
     rng = np.random.RandomState(1)
     r5 = _rois(rng, 20, 2, 13, 17)
@@ -260,3 +262,27 @@ def test_inference_keeps_the_projected_map_across_head_calls(dev):
     assert 'entry' not in C._proj_cache                    # recorded graph: projections inside the node
     out[0].sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+def test_head_with_no_rois_and_training_mode_row_subset(dev):
+    """Edge cases of the head's projected path: an empty RoI set takes the reference-order branch
+    (nothing to pool), and a recorded graph with a mask-row subset trains (finite gradients for the
+    map and for res5.a's two projections)."""
+    import chainer_mask_rcnn_amd as cmr
+    torch.manual_seed(0)
+    head = cmr.models.mask_rcnn_resnet.ResNetRoIHead(50, 5, 14, 1 / 16.).to(dev)
+    x = nhwc(torch.randn((1, 1024, 9, 11), device=dev)).requires_grad_(True)
+    rng = np.random.RandomState(2)
+    r5 = _rois(rng, 12, 1, 9, 11)
+    rois = torch.tensor(r5[:, [2, 1, 4, 3]], device=dev)
+    idx = torch.tensor(r5[:, 0].astype(np.int32), device=dev)
+    rows = torch.tensor([1, 4, 7], dtype=torch.int64, device=dev)
+    locs, scores, masks = head(x, rois, idx, mask_rows=rows)
+    assert tuple(locs.shape) == (12, 20) and tuple(masks.shape) == (3, 4, 14, 14)
+    (locs.sum() + scores.sum() + masks.sum()).backward()
+    a = head.res5.a
+    for t in (x.grad, a.conv1.W.grad, a.conv4.W.grad):
+        assert t is not None and torch.isfinite(t).all() and float(t.abs().sum()) > 0
+    with torch.no_grad():
+        out = head(x.detach(), rois[:0], idx[:0])
+    assert out[0].shape[0] == 0 and out[2].shape[0] == 0
