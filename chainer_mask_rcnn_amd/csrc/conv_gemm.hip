@@ -1587,8 +1587,9 @@ int g_extra_lds = 0;   // developer knob: dynamic LDS bytes added to every GEMM 
 int g_split_bf16 = 3;  // mrcnn_set_tuning("split_bf16"): bit 0 = 128x128 kernels, bit 1 = 64x64 forward form on the
                        // split-operand arithmetic (see SPLIT; the default since round 4), 0 = fp32 MFMA everywhere
 int g_stagger = 0;    // mrcnn_set_tuning("stagger", percent of the nominal start-up stagger; 0 = off)
-int g_big_split_k = 0;  // mrcnn_set_tuning("big_split_k"): small-M problems as 128x128 tiles cut along K.
-                      // 0 (default) = off (64x64 tiles), -1 = the rule in launch(), k > 0 = aim at k workgroups
+int g_big_split_k = -1; // mrcnn_set_tuning("big_split_k"): small-M problems as 128x128 tiles cut along K.
+                      // -1 (default since round 6) = the one-round rule in launch(), 0 = off (64x64 tiles),
+                      // k > 0 = aim at k workgroups
 int g_stagger_min_rounds = 2;
 int g_w8_min_k = 256; // mrcnn_set_tuning("w8_min_k"): shallowest K (input channels) a W8 launch takes
 int g_w8 = 1;         // mrcnn_set_tuning("w8", 0/1): 256x128 tiles on 512-thread workgroups (W8) for the large
@@ -1991,8 +1992,9 @@ int launch(const GemmParams &p0, int splits, hipStream_t s)
     // into ONE round of the 512 resident workgroups at >= 75 % fill with >= 16 slices each, the
     // 128x128 kernel plus the ordered slab sum is faster in isolation (98 -> 83 us forward, 97 -> 80 us
     // data gradient, profiles/r05d_big_split_k.txt); other counts land in a nearly empty second round
-    // and lose.  In the train step the rule is worth 0.05 - 0.1 ms of 26 (same-box A/B,
-    // profiles/r05_ab_big_split_k.txt): opt-in ("big_split_k" = -1), not the default.
+    // and lose.  In the R-50 train step the rule is worth 0.05 - 0.1 ms (12 launches), in the R-101
+    // step (46 launches: 23 res4 blocks) 0.39 ms of 32.1 (same-box A/B, profiles/r06e_ab_big_split_k.txt):
+    // the default since round 6 ("big_split_k" = 0 restores the 64x64 tiles).
     const int total_slices_ = p.R * p.S * (int)mrcnn::ceil_div(p.Kc, BK);
     int64_t ksplits = 1;
     if (g_big_split_k != 0 && big_ok && T < g_big_min_tiles && splits == 1 && can_split_rows<MODE>(p)) {

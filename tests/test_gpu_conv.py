@@ -443,17 +443,17 @@ def test_fused_stage_matches_bottleneck_chain(dev, shape, chans, stride):
     (1, 64, 67, 131, 64, 1),       # only 2 K slices: no split (too shallow)
 ])
 @pytest.mark.parametrize('big_split_k', [0, -1, 512],
-                         ids=['64x64 tiles (shipped)', 'one-round rule', '128x128 tiles cut along K'])
+                         ids=['64x64 tiles', 'one-round rule (shipped)', '128x128 tiles cut along K'])
 def test_small_m_split_k_leftover_rows(dev, case, big_split_k):
     """The small-M tile policies of csrc/conv_gemm.hip launch(): 64x64 tiles with K-split leftover
-    rows (shipped), and 128x128 tiles cut along K over all rows (opt-in: the one-round rule picks them
+    rows and 128x128 tiles cut along K over all rows (the shipped one-round rule picks them
     for the res4 3x3 shape) — forward with the whole fused epilogue and every gradient vs float64."""
     from chainer_mask_rcnn_amd import _lib
     _lib.set_tuning('big_split_k', big_split_k)
     try:
         _small_m_case(dev, case)
     finally:
-        _lib.set_tuning('big_split_k', 0)
+        _lib.set_tuning('big_split_k', -1)     # the library's default
 
 
 def _small_m_case(dev, case):

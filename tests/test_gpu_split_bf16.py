@@ -108,7 +108,7 @@ def test_fused_bottleneck(dev, split, proj, stride):
 
 @pytest.mark.parametrize('case', [(2, 256, 51, 84, 256, 3), (2, 1024, 51, 84, 256, 1)])
 def test_split_k_tails(dev, split, case):
-    for big_split_k in (0, -1):          # 64x64 tiles (shipped) and the opt-in 128x128 tiles cut along K
+    for big_split_k in (0, -1):          # 64x64 tiles and the 128x128 tiles cut along K (one-round rule, shipped)
         TC.test_small_m_split_k_leftover_rows(dev, case, big_split_k)
 
 
