@@ -1591,6 +1591,7 @@ int g_big_split_k = -1; // mrcnn_set_tuning("big_split_k"): small-M problems as 
                       // -1 (default since round 6) = the one-round rule in launch(), 0 = off (64x64 tiles),
                       // k > 0 = aim at k workgroups
 int g_stagger_min_rounds = 2;
+int g_big_split_min_slices = 16;   // mrcnn_set_tuning("big_split_min_slices"): fewest K slices per slab of the one-round rule
 int g_w8_min_k = 256; // mrcnn_set_tuning("w8_min_k"): shallowest K (input channels) a W8 launch takes
 int g_w8 = 1;         // mrcnn_set_tuning("w8", 0/1): 256x128 tiles on 512-thread workgroups (W8) for the large
                       // pointwise forward-form launches of the split-operand arithmetic
@@ -2002,7 +2003,7 @@ int launch(const GemmParams &p0, int splits, hipStream_t s)
             ksplits = std::min<int64_t>(std::min<int64_t>(8, total_slices_ / 8), mrcnn::ceil_div(g_big_split_k, T));
         } else {
             const int64_t fit = kSlotsBig / T;                 // splits that still make one round
-            if (fit >= 2 && fit <= 8 && T * fit >= kSlotsBig * 3 / 4 && total_slices_ / fit >= 16) ksplits = fit;
+            if (fit >= 2 && fit <= 8 && T * fit >= kSlotsBig * 3 / 4 && total_slices_ / fit >= g_big_split_min_slices) ksplits = fit;
         }
         while (ksplits > 1 && (int64_t)p.M * p.N * ksplits * 4 > kSplitWsBytes) --ksplits;
     }
@@ -2169,6 +2170,10 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "big_split_k") == 0) {
         g_big_split_k = value;
+        return 0;
+    }
+    if (strcmp(name, "big_split_min_slices") == 0) {
+        g_big_split_min_slices = value;
         return 0;
     }
     if (strcmp(name, "w8") == 0) {
