@@ -484,6 +484,7 @@ def preflight_allreduce(exchange, rank, world, device, timeout_s=60.0):
 
     def run():
         try:
+            torch.cuda.set_device(device)       # (a new thread starts on device 0)
             exchange.allreduce_async(t, -3)
             exchange.wait_all()
             torch.cuda.synchronize(device)
