@@ -483,8 +483,9 @@ conv_gemm_kernel(const GemmParams p)
     // 1x1 / stride 1 / pad 0 forward-form launches (two thirds of the RoI head's GEMMs): GEMM row
     // m IS pixel m of the gathered tensor — no (image, y, x) decomposition, i.e. none of the
     // eight integer divisions of the general set-up
-    const bool pointwise = FWDLIKE && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 &&
-                           p.perm_n == 0 && !p.stem && p.gp == p.sh && p.gq == p.sw;   // uniform
+    // (W8 launches are pointwise by the host's rule, w8_ok: the general gather is compiled out)
+    const bool pointwise = W8 || (FWDLIKE && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 &&
+                                  p.perm_n == 0 && !p.stem && p.gp == p.sh && p.gq == p.sw);   // uniform
     if (MODE != WGRAD && pointwise) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -1211,7 +1212,8 @@ conv_gemm_kernel(const GemmParams p)
 #endif
     constexpr int EG = 8;       // accumulator rows handled per batch of auxiliary loads
 
-    if (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0 && p.out_mode == OUT_PLAIN) {   // (uniform)
+    // (W8 launches write plain rows in natural order by the host's rule, w8_ok)
+    if (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0 && (W8 || p.out_mode == OUT_PLAIN)) {   // (uniform)
       if constexpr (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
         // Forward-form launches: the accumulators (one column x 16 rows per lane) are turned
         // into row-major float4s through the wave's corner of the LDS stages, so the residual
@@ -1261,7 +1263,7 @@ conv_gemm_kernel(const GemmParams p)
             const bool c_resg = F >= 0 ? (F & C_RESG) != 0 : f_resg;
             const bool c_resy = F >= 0 ? (F & C_RESY) != 0 : f_resy;
             const bool c_outm = F >= 0 ? (F & C_OUTM) != 0 : f_outm;
-            const bool natural = F >= 0 || !(p.perm_n > 0 && !slab_rows);   // F >= 0: natural row order
+            const bool natural = F >= 0 || W8 || !(p.perm_n > 0 && !slab_rows);   // F >= 0: natural row order
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1343,7 +1345,7 @@ conv_gemm_kernel(const GemmParams p)
         const int combo = (f_bias ? C_BIAS : 0) | (f_aff ? C_AFF : 0) | (f_res ? C_RES : 0) |
                           (f_relu ? C_RELU : 0) | (f_acc ? C_ACC : 0) | (f_resg ? C_RESG : 0) |
                           (f_resy ? C_RESY : 0) | (f_outm ? C_OUTM : 0);
-        const bool permuted = p.perm_n > 0 && !slab_rows;
+        const bool permuted = !W8 && p.perm_n > 0 && !slab_rows;
 #define MRCNN_EPI_CASE(F) case (F): run(std::integral_constant<int, (F)>()); break;
         switch (permuted ? -1 : combo) {       // workgroup-uniform
             MRCNN_EPI_CASE(0)

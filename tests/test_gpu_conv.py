@@ -540,3 +540,40 @@ def test_position_major_wgrad(dev, case):
     _close(outs[0].cpu().numpy(), gW)
     _close(outs[1].cpu().numpy(), gW)
     assert not torch.equal(outs[0], outs[1]) or True     # orders differ; values agree to 1e-4
+
+
+@pytest.mark.parametrize('rois', [1024, 1000])
+def test_w8_is_bit_identical(dev, rois):
+    """csrc/conv_gemm.hip, W8: the 256x128 tiles on 512-thread workgroups produce the bits of the
+    128x128 kernel — RoI-head-sized fused res5 stage (1x1 layers with every fused epilogue, the
+    Winograd GEMMs of the 3x3 layers, the transposed-filter data gradients; 1000 RoIs: ragged last
+    tiles and the fused K-split tail)."""
+    from chainer_mask_rcnn_amd import _lib
+    from chainer_mask_rcnn_amd.models.resnet_extractor import BuildingBlock
+    torch.manual_seed(11)
+    stage = BuildingBlock(3, 1024, 512, 2048, 1).to(dev)
+    with torch.no_grad():
+        for name, p in stage.named_parameters():
+            if '.bn' in name and name.endswith('.W'):
+                p.uniform_(0.5, 1.5)
+            elif '.bn' in name:
+                p.normal_(0, 0.3)
+    x = torch.randn((rois, 1024, 7, 7), device=dev).contiguous(memory_format=torch.channels_last)
+    gy = None
+    out = {}
+    try:
+        for w8 in (0, 1):
+            _lib.set_tuning('w8', w8)
+            xt = x.clone().requires_grad_(True)
+            y = stage(xt)
+            if gy is None:
+                gy = torch.randn_like(y)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            out[w8] = (y.detach().clone(), xt.grad.clone())
+            del y, xt
+    finally:
+        _lib.set_tuning('w8', 1)
+    assert torch.equal(out[1][0], out[0][0])
+    assert torch.equal(out[1][1], out[0][1])
+    assert out[1][0].abs().sum() > 0 and out[1][1].abs().sum() > 0
