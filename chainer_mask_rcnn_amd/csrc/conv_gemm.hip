@@ -372,7 +372,14 @@ __device__ __forceinline__ void sgb_interleave()
 // multiply slice k and then split / store slice k + 1, waves 4-7 store first and multiply afterwards
 // (both orders read stage k & 1 and write the other one, so the interval needs no further
 // synchronisation); a SIMD hosts one wave of each half (MI355X_MICROARCH.md, wave placement).
-template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false, bool W8 = false>
+//
+// PW (forward form): the launch is a 1x1 / stride 1 / pad 0 gather in natural row order that writes
+// plain rows (pw_plain() on the host) — the general gather (taps, image / y / x decomposition,
+// position-major rows) and the strided / deconvolution output maps are compiled out, which frees
+// the scalar registers the general instantiation spills (W8: 87 -> 0 spilled SGPRs, 250 -> 182
+// VGPRs, +3 % on the head's 1x1 layers).  W8 implies it.  Same arithmetic, same bits.
+template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false, bool W8 = false,
+          bool PW = false>
 __global__ void __launch_bounds__(W8 ? 512 : 256,
                                   SPLIT ? (TM == 2 ? 2 : 4) : min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
@@ -380,6 +387,8 @@ conv_gemm_kernel(const GemmParams p)
     static_assert(!W8 || (SPLIT && MODE == FWD && TM == 2 && TN == 2 && !MASKED),
                   "W8: the split-operand forward form on 64x64 wave tiles, unmasked");
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
+    static_assert(!PW || MODE == FWD, "PW: forward form only");
+    constexpr bool PWC = W8 || PW;
     constexpr bool ILV = MRCNN_SPLIT_ILV != 0 && SPLIT && MODE == FWD && !MASKED;
     static_assert(!SPLIT || (BK == 32 && TM == TN &&
                              ((MODE == FWD && (TM == 1 || TM == 2)) || (MODE == WGRAD && !WPERM && TM == 2))),
@@ -483,8 +492,8 @@ conv_gemm_kernel(const GemmParams p)
     // 1x1 / stride 1 / pad 0 forward-form launches (two thirds of the RoI head's GEMMs): GEMM row
     // m IS pixel m of the gathered tensor — no (image, y, x) decomposition, i.e. none of the
     // eight integer divisions of the general set-up
-    // (W8 launches are pointwise by the host's rule, w8_ok: the general gather is compiled out)
-    const bool pointwise = W8 || (FWDLIKE && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 &&
+    // (PW / W8 launches are pointwise by the host's rule: the general gather is compiled out)
+    const bool pointwise = PWC || (FWDLIKE && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 &&
                                   p.perm_n == 0 && !p.stem && p.gp == p.sh && p.gq == p.sw);   // uniform
     if (MODE != WGRAD && pointwise) {
 #pragma unroll
@@ -580,7 +589,7 @@ conv_gemm_kernel(const GemmParams p)
     // tile, as 4-bit indices packed into a word (wave-uniform)
     int ntaps = p.R * p.S;
     unsigned long long tap_list = 0;
-    if (FWDLIKE && p.perm_n > 0) {
+    if (FWDLIKE && !PWC && p.perm_n > 0) {
         const int q_lo = m0 / kPermBlock;
         const int q_hi = min(p.M - 1, m0 + BM - 1) / kPermBlock;
         const int pq = p.gp * p.gq;
@@ -1212,8 +1221,8 @@ conv_gemm_kernel(const GemmParams p)
 #endif
     constexpr int EG = 8;       // accumulator rows handled per batch of auxiliary loads
 
-    // (W8 launches write plain rows in natural order by the host's rule, w8_ok)
-    if (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0 && (W8 || p.out_mode == OUT_PLAIN)) {   // (uniform)
+    // (PW / W8 launches write plain rows in natural order by the host's rule)
+    if (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0 && (PWC || p.out_mode == OUT_PLAIN)) {   // (uniform)
       if constexpr (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
         // Forward-form launches: the accumulators (one column x 16 rows per lane) are turned
         // into row-major float4s through the wave's corner of the LDS stages, so the residual
@@ -1263,7 +1272,7 @@ conv_gemm_kernel(const GemmParams p)
             const bool c_resg = F >= 0 ? (F & C_RESG) != 0 : f_resg;
             const bool c_resy = F >= 0 ? (F & C_RESY) != 0 : f_resy;
             const bool c_outm = F >= 0 ? (F & C_OUTM) != 0 : f_outm;
-            const bool natural = F >= 0 || W8 || !(p.perm_n > 0 && !slab_rows);   // F >= 0: natural row order
+            const bool natural = F >= 0 || PWC || !(p.perm_n > 0 && !slab_rows);   // F >= 0: natural row order
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1345,7 +1354,7 @@ conv_gemm_kernel(const GemmParams p)
         const int combo = (f_bias ? C_BIAS : 0) | (f_aff ? C_AFF : 0) | (f_res ? C_RES : 0) |
                           (f_relu ? C_RELU : 0) | (f_acc ? C_ACC : 0) | (f_resg ? C_RESG : 0) |
                           (f_resy ? C_RESY : 0) | (f_outm ? C_OUTM : 0);
-        const bool permuted = !W8 && p.perm_n > 0 && !slab_rows;
+        const bool permuted = !PWC && p.perm_n > 0 && !slab_rows;
 #define MRCNN_EPI_CASE(F) case (F): run(std::integral_constant<int, (F)>()); break;
         switch (permuted ? -1 : combo) {       // workgroup-uniform
             MRCNN_EPI_CASE(0)
@@ -1402,11 +1411,11 @@ conv_gemm_kernel(const GemmParams p)
         const int colc = col_ok ? col : 0;
         float bias = 0.f, scale = 1.f, shift = 0.f;
         if (MODE != WGRAD) {
-            if (f_bias) bias = p.bias[p.out_mode == OUT_DECONV ? colc % p.ko : colc];
+            if (f_bias) bias = p.bias[!PWC && p.out_mode == OUT_DECONV ? colc % p.ko : colc];
             if (f_aff) { scale = p.scale[colc]; shift = p.shift ? p.shift[colc] : 0.f; }
         }
         int col_off = colc;
-        if (MODE != WGRAD && p.out_mode == OUT_DECONV) {
+        if (MODE != WGRAD && !PWC && p.out_mode == OUT_DECONV) {
             const int ab = colc / p.ko, o = colc - ab * p.ko;
             col_off = ((ab >> 1) * (2 * p.gq) + (ab & 1)) * p.ko + o;
         }
@@ -1420,7 +1429,7 @@ conv_gemm_kernel(const GemmParams p)
                     const int e = g * EG + q;
                     const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                     int o;
-                    if (MODE != WGRAD && p.out_mode != OUT_PLAIN) {
+                    if (MODE != WGRAD && !PWC && p.out_mode != OUT_PLAIN) {
                         const int rr = row < p.M ? row : 0;
                         const int n = rr / (p.gp * p.gq);
                         const int rem = rr - n * (p.gp * p.gq);
@@ -1430,7 +1439,7 @@ conv_gemm_kernel(const GemmParams p)
                                  gx * (p.ostride ? p.ostride : p.stride)) * p.ldc + col_off;
                         else
                             o = ((n * (2 * p.gp) + 2 * gy) * (2 * p.gq) + 2 * gx) * p.ko + col_off;
-                    } else if (FWDLIKE && p.perm_n > 0 && !slab_rows) {
+                    } else if (FWDLIKE && !PWC && p.perm_n > 0 && !slab_rows) {
                         // position-major GEMM row -> (image, position) row of the NHWC tensor
                         // (split-K slabs stay indexed by GEMM row; the slab-sum kernel maps)
                         const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
@@ -1598,6 +1607,15 @@ int g_w8_min_k = 256; // mrcnn_set_tuning("w8_min_k"): shallowest K (input chann
 int g_w8 = 1;         // mrcnn_set_tuning("w8", 0/1): 256x128 tiles on 512-thread workgroups (W8) for the large
                       // pointwise forward-form launches of the split-operand arithmetic
 
+int g_pw = 1;         // mrcnn_set_tuning("pw", 0/1): the PW instantiations for pointwise forward-form launches
+
+// PW's launch rule (see the note above conv_gemm_kernel)
+inline bool pw_plain(const GemmParams &p)
+{
+    return p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.perm_n == 0 && !p.stem && p.gp == p.sh &&
+           p.gq == p.sw && p.out_mode == OUT_PLAIN;
+}
+
 template <int TM, int TN, int MODE, bool MASKED>
 void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_t s, int batch = 1)
 {
@@ -1643,9 +1661,14 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
     }
     if constexpr (MODE == FWD && TM == TN && (TM == 1 || TM == 2)) {
         if (g_split_bf16 & (TM == 2 ? 1 : 2)) {
-            hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
-                               dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1, 0,
-                                  p);
+            if (g_pw && pw_plain(p))
+                hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true, false, true>),
+                                      dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1,
+                                      0, p);
+            else
+                hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true>),
+                                      dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1,
+                                      0, p);
             return;
         }
     }
@@ -2184,6 +2207,10 @@ extern "C" int mrcnn_set_tuning(const char *name, int value)
     }
     if (strcmp(name, "w8_min_k") == 0) {
         g_w8_min_k = value;
+        return 0;
+    }
+    if (strcmp(name, "pw") == 0) {
+        g_pw = value;
         return 0;
     }
     if (strcmp(name, "tiny_split") == 0) {
