@@ -377,9 +377,11 @@ __device__ __forceinline__ void sgb_interleave()
 // plain rows (pw_plain() on the host) — the general gather (taps, image / y / x decomposition,
 // position-major rows) and the strided / deconvolution output maps are compiled out, which frees
 // the scalar registers the general instantiation spills (W8: 87 -> 0 spilled SGPRs, 250 -> 182
-// VGPRs, +3 % on the head's 1x1 layers).  W8 implies it.  Same arithmetic, same bits.
+// VGPRs, +3 % on the head's 1x1 layers).  W8 implies it.  K3: the same for the 3x3 / stride 1 / pad 1
+// launches in natural row order (k3_plain(): the backbone's 3x3 layers and their transposed-filter data
+// gradients) — filter size, stride and padding are constants of the gather.  Same arithmetic, same bits.
 template <int TM, int TN, int MODE, bool MASKED, bool WPERM = false, bool SPLIT = false, bool W8 = false,
-          bool PW = false>
+          bool PW = false, bool K3 = false>
 __global__ void __launch_bounds__(W8 ? 512 : 256,
                                   SPLIT ? (TM == 2 ? 2 : 4) : min_blocks(TM, MODE, MASKED))
 conv_gemm_kernel(const GemmParams p)
@@ -388,7 +390,15 @@ conv_gemm_kernel(const GemmParams p)
                   "W8: the split-operand forward form on 64x64 wave tiles, unmasked");
     static_assert(!WPERM || (MODE == WGRAD && !MASKED), "WPERM is a WGRAD-only variant");
     static_assert(!PW || MODE == FWD, "PW: forward form only");
+    static_assert(!K3 || (MODE == FWD && !W8 && !PW), "K3: forward form only");
     constexpr bool PWC = W8 || PW;
+    // the launch geometry the gather and the output map use: compile-time facts in the PW / K3
+    // instantiations (natural row order, no stem packing, plain output rows), the launch's fields otherwise
+    constexpr bool GEO = PWC || K3;
+    const int gR = PWC ? 1 : K3 ? 3 : p.R, gS = PWC ? 1 : K3 ? 3 : p.S;
+    const int gStride = GEO ? 1 : p.stride, gPad = PWC ? 0 : K3 ? 1 : p.pad;
+    const int gPermN = GEO ? 0 : p.perm_n;
+    const bool gStem = !GEO && p.stem;
     constexpr bool ILV = MRCNN_SPLIT_ILV != 0 && SPLIT && MODE == FWD && !MASKED;
     static_assert(!SPLIT || (BK == 32 && TM == TN &&
                              ((MODE == FWD && (TM == 1 || TM == 2)) || (MODE == WGRAD && !WPERM && TM == 2))),
@@ -493,8 +503,8 @@ conv_gemm_kernel(const GemmParams p)
     // m IS pixel m of the gathered tensor — no (image, y, x) decomposition, i.e. none of the
     // eight integer divisions of the general set-up
     // (PW / W8 launches are pointwise by the host's rule: the general gather is compiled out)
-    const bool pointwise = PWC || (FWDLIKE && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 &&
-                                  p.perm_n == 0 && !p.stem && p.gp == p.sh && p.gq == p.sw);   // uniform
+    const bool pointwise = PWC || (FWDLIKE && gR == 1 && gS == 1 && gStride == 1 && gPad == 0 &&
+                                  gPermN == 0 && !gStem && p.gp == p.sh && p.gq == p.sw);   // uniform
     if (MODE != WGRAD && pointwise) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -514,17 +524,17 @@ conv_gemm_kernel(const GemmParams p)
             const int mm = ok ? m : 0;
             int n, rem;
             bool img_ok = true;
-            if (FWDLIKE && p.perm_n > 0) {
+            if (FWDLIKE && gPermN > 0) {
                 const PermRow pr = perm_row(mm, p.gp * p.gq);
                 n = pr.n; rem = pr.pos;
-                img_ok = n < p.perm_n;           // padding rows of the last image block
+                img_ok = n < gPermN;           // padding rows of the last image block
             } else {
                 n = mm / (p.gp * p.gq); rem = mm - n * (p.gp * p.gq);
             }
             const int gy = rem / p.gq, gx = rem - gy * p.gq;
             a_n[i] = n;
-            if (FWDLIKE) { a_y[i] = gy * p.stride - p.pad; a_x[i] = gx * p.stride - p.pad; }
-            else { a_y[i] = gy + p.pad; a_x[i] = gx + p.pad; }
+            if (FWDLIKE) { a_y[i] = gy * gStride - gPad; a_x[i] = gx * gStride - gPad; }
+            else { a_y[i] = gy + gPad; a_x[i] = gx + gPad; }
             if (!ok || !img_ok) a_y[i] = -(1 << 28);   // no such row: every tap out of range
         }
     }
@@ -549,8 +559,8 @@ conv_gemm_kernel(const GemmParams p)
         const int jj = wcol_ok ? j : 0;
         const int rs = jj / p.cin;
         wc = jj - rs * p.cin;
-        wr = rs / p.S;
-        ws_ = rs - wr * p.S;
+        wr = rs / gS;
+        ws_ = rs - wr * gS;
         k_begin = split * p.split_len;
         if (WPERM) {
             // Pixel order for the reduction: (block of BK images, position, image in block),
@@ -560,12 +570,12 @@ conv_gemm_kernel(const GemmParams p)
             // same tap (cin % BN == 0, checked by the host): tile-uniform values live in SGPRs.
             wr_u = __builtin_amdgcn_readfirstlane(wr);
             ws_u = __builtin_amdgcn_readfirstlane(ws_);
-            wy_lo = max(0, p.pad - wr_u);
-            wx_lo = max(0, p.pad - ws_u);
-            const int nvy = min(p.gp - 1, p.sh - 1 + p.pad - wr_u) - wy_lo + 1;
-            wnvx = max(min(p.gq - 1, p.sw - 1 + p.pad - ws_u) - wx_lo + 1, 0);
+            wy_lo = max(0, gPad - wr_u);
+            wx_lo = max(0, gPad - ws_u);
+            const int nvy = min(p.gp - 1, p.sh - 1 + gPad - wr_u) - wy_lo + 1;
+            wnvx = max(min(p.gq - 1, p.sw - 1 + gPad - ws_u) - wx_lo + 1, 0);
             wnv = max(nvy, 0) * wnvx;
-            const int nblk = (p.perm_n + BK - 1) / BK;
+            const int nblk = (gPermN + BK - 1) / BK;
             k_end = min(nblk * wnv * BK, k_begin + p.split_len);
         } else {
             k_end = min(p.Kc, k_begin + p.split_len);
@@ -587,21 +597,21 @@ conv_gemm_kernel(const GemmParams p)
     // runs slices [kt0, kt0 + nslices) and writes raw partial sums into its slab
     // position-major rows: the taps that are inside the map for at least one position of this
     // tile, as 4-bit indices packed into a word (wave-uniform)
-    int ntaps = p.R * p.S;
+    int ntaps = gR * gS;
     unsigned long long tap_list = 0;
-    if (FWDLIKE && !PWC && p.perm_n > 0) {
+    if (FWDLIKE && !GEO && gPermN > 0) {
         const int q_lo = m0 / kPermBlock;
         const int q_hi = min(p.M - 1, m0 + BM - 1) / kPermBlock;
         const int pq = p.gp * p.gq;
         ntaps = 0;
-        for (int rs = 0; rs < p.R * p.S; ++rs) {
-            const int r = rs / p.S, s = rs - r * p.S;
+        for (int rs = 0; rs < gR * gS; ++rs) {
+            const int r = rs / gS, s = rs - r * gS;
             bool hit = q_hi - q_lo > 3;              // many positions in the tile: keep all
             for (int qq = q_lo; qq <= q_hi && !hit; ++qq) {
                 const int q = qq % pq;
                 const int y = q / p.gq, x = q - y * p.gq;
-                hit = (unsigned)(y * p.stride - p.pad + r) < (unsigned)p.sh &&
-                      (unsigned)(x * p.stride - p.pad + s) < (unsigned)p.sw;
+                hit = (unsigned)(y * gStride - gPad + r) < (unsigned)p.sh &&
+                      (unsigned)(x * gStride - gPad + s) < (unsigned)p.sw;
             }
             if (hit) {
                 tap_list |= (unsigned long long)rs << (4 * ntaps);
@@ -670,9 +680,9 @@ conv_gemm_kernel(const GemmParams p)
                 b_base[i] = wcol_ok ? (unsigned)(b_krow(i) * p.lda + wc) : kBad;
         }
     }
-    const bool wpoint = MODE == WGRAD && !WPERM && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 &&
+    const bool wpoint = MODE == WGRAD && !WPERM && gR == 1 && gS == 1 && gStride == 1 && gPad == 0 &&
                         p.gp == p.sh && p.gq == p.sw;      // uniform
-    const int RS = p.R * p.S;
+    const int RS = gR * gS;
 
     // ILV (SPLIT forward form without mask staging): load_slice only computes the byte offsets of
     // the slice's loads; the loads themselves are issued INSIDE the following compute(), spread
@@ -732,7 +742,7 @@ conv_gemm_kernel(const GemmParams p)
         if (FWDLIKE || MODE == DGRAD) {
             kt += kt0;
             int chunk, rs;
-            if (FWDLIKE && p.perm_n > 0) {
+            if (FWDLIKE && gPermN > 0) {
                 chunk = kt / ntaps;
                 rs = (int)((tap_list >> (4 * (kt - chunk * ntaps))) & 15ull);
             } else {
@@ -740,15 +750,15 @@ conv_gemm_kernel(const GemmParams p)
                 rs = kt - chunk * RS;
             }
             const int c0 = chunk * BK;
-            const int r = rs / p.S, s = rs - r * p.S;
+            const int r = rs / gS, s = rs - r * gS;
             const int cc = c0 + kc_c4 * 4;
-            const bool c_ok = p.stem || cc < p.Kc;
+            const bool c_ok = gStem || cc < p.Kc;
             // wave-uniform part of the A address for this slice
             const int tap = (FWDLIKE ? (r * p.sw + s) : -(r * p.sw + s)) * p.lda + c0;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 int iy, ix;
-                if (FWDLIKE) { iy = a_y[i] + r; ix = a_x[i] + s + (p.stem ? (cc >> 2) : 0); }
+                if (FWDLIKE) { iy = a_y[i] + r; ix = a_x[i] + s + (gStem ? (cc >> 2) : 0); }
                 else { iy = a_y[i] - r; ix = a_x[i] - s; }
                 const bool ok = c_ok && (unsigned)iy < (unsigned)p.sh && (unsigned)ix < (unsigned)p.sw;
                 ldA(i, ok ? 4u * (a_base[i] + (unsigned)tap) : kOOB);
@@ -779,12 +789,12 @@ conv_gemm_kernel(const GemmParams p)
                 const int y = wy_lo + yv, x = wx_lo + pos - yv * wnvx;
                 const int a_col = m0 + wa_c4 * 4;
                 const int pix_a = y * p.gq + x;
-                const int pix_b = (y + wr_u - p.pad) * p.sw + x + ws_u - p.pad;
+                const int pix_b = (y + wr_u - gPad) * p.sw + x + ws_u - gPad;
 #pragma unroll
                 for (int i = 0; i < BV; ++i) {
                     const int r = wb_k + B_RPP * i;
                     const int n = blk * BK + r;
-                    const bool ok = kb + r < k_end && n < p.perm_n;
+                    const bool ok = kb + r < k_end && n < gPermN;
                     const unsigned offa = (unsigned)((n * (p.gp * p.gq) + pix_a) * p.ldg + a_col);
                     ra[i] = bload4(rA, ok && a_col < p.M ? 4u * offa : kOOB);
                     const unsigned offb = (unsigned)((n * (p.sh * p.sw) + pix_b) * p.lda + wc);
@@ -813,8 +823,8 @@ conv_gemm_kernel(const GemmParams p)
 #pragma unroll
             for (int i = 0; i < BV; ++i) {
                 const int m = kb + b_krow(i);
-                const int iy = py[i] * p.stride - p.pad + wr;
-                const int ix = px[i] * p.stride - p.pad + ws_;
+                const int iy = py[i] * gStride - gPad + wr;
+                const int ix = px[i] * gStride - gPad + ws_;
                 const bool ok = wcol_ok && m < k_end && (unsigned)iy < (unsigned)p.sh &&
                                 (unsigned)ix < (unsigned)p.sw;
                 rb[i] = bload4(rB, ok ? 4u * (unsigned)(((pn[i] * p.sh + iy) * p.sw + ix) * p.lda + wc)
@@ -1222,7 +1232,7 @@ conv_gemm_kernel(const GemmParams p)
     constexpr int EG = 8;       // accumulator rows handled per batch of auxiliary loads
 
     // (PW / W8 launches write plain rows in natural order by the host's rule)
-    if (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0 && (PWC || p.out_mode == OUT_PLAIN)) {   // (uniform)
+    if (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0 && (GEO || p.out_mode == OUT_PLAIN)) {   // (uniform)
       if constexpr (MODE == FWD && TM >= 2 && MRCNN_GEMM_WIDE_EPILOGUE != 0) {
         // Forward-form launches: the accumulators (one column x 16 rows per lane) are turned
         // into row-major float4s through the wave's corner of the LDS stages, so the residual
@@ -1272,7 +1282,7 @@ conv_gemm_kernel(const GemmParams p)
             const bool c_resg = F >= 0 ? (F & C_RESG) != 0 : f_resg;
             const bool c_resy = F >= 0 ? (F & C_RESY) != 0 : f_resy;
             const bool c_outm = F >= 0 ? (F & C_OUTM) != 0 : f_outm;
-            const bool natural = F >= 0 || PWC || !(p.perm_n > 0 && !slab_rows);   // F >= 0: natural row order
+            const bool natural = F >= 0 || GEO || !(gPermN > 0 && !slab_rows);   // F >= 0: natural row order
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1295,7 +1305,7 @@ conv_gemm_kernel(const GemmParams p)
                         int orow;
                         if (!natural) {
                             const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
-                            orow = pr.n < p.perm_n ? pr.n * (p.gp * p.gq) + pr.pos : -1;
+                            orow = pr.n < gPermN ? pr.n * (p.gp * p.gq) + pr.pos : -1;
                         } else {
                             orow = row - e_row0;
                         }
@@ -1354,7 +1364,7 @@ conv_gemm_kernel(const GemmParams p)
         const int combo = (f_bias ? C_BIAS : 0) | (f_aff ? C_AFF : 0) | (f_res ? C_RES : 0) |
                           (f_relu ? C_RELU : 0) | (f_acc ? C_ACC : 0) | (f_resg ? C_RESG : 0) |
                           (f_resy ? C_RESY : 0) | (f_outm ? C_OUTM : 0);
-        const bool permuted = !PWC && p.perm_n > 0 && !slab_rows;
+        const bool permuted = !GEO && gPermN > 0 && !slab_rows;
 #define MRCNN_EPI_CASE(F) case (F): run(std::integral_constant<int, (F)>()); break;
         switch (permuted ? -1 : combo) {       // workgroup-uniform
             MRCNN_EPI_CASE(0)
@@ -1411,11 +1421,11 @@ conv_gemm_kernel(const GemmParams p)
         const int colc = col_ok ? col : 0;
         float bias = 0.f, scale = 1.f, shift = 0.f;
         if (MODE != WGRAD) {
-            if (f_bias) bias = p.bias[!PWC && p.out_mode == OUT_DECONV ? colc % p.ko : colc];
+            if (f_bias) bias = p.bias[!GEO && p.out_mode == OUT_DECONV ? colc % p.ko : colc];
             if (f_aff) { scale = p.scale[colc]; shift = p.shift ? p.shift[colc] : 0.f; }
         }
         int col_off = colc;
-        if (MODE != WGRAD && !PWC && p.out_mode == OUT_DECONV) {
+        if (MODE != WGRAD && !GEO && p.out_mode == OUT_DECONV) {
             const int ab = colc / p.ko, o = colc - ab * p.ko;
             col_off = ((ab >> 1) * (2 * p.gq) + (ab & 1)) * p.ko + o;
         }
@@ -1429,21 +1439,21 @@ conv_gemm_kernel(const GemmParams p)
                     const int e = g * EG + q;
                     const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                     int o;
-                    if (MODE != WGRAD && !PWC && p.out_mode != OUT_PLAIN) {
+                    if (MODE != WGRAD && !GEO && p.out_mode != OUT_PLAIN) {
                         const int rr = row < p.M ? row : 0;
                         const int n = rr / (p.gp * p.gq);
                         const int rem = rr - n * (p.gp * p.gq);
                         const int gy = rem / p.gq, gx = rem - gy * p.gq;
                         if (p.out_mode == OUT_STRIDED)
-                            o = ((n * p.oh + gy * (p.ostride ? p.ostride : p.stride)) * p.ow +
-                                 gx * (p.ostride ? p.ostride : p.stride)) * p.ldc + col_off;
+                            o = ((n * p.oh + gy * (p.ostride ? p.ostride : gStride)) * p.ow +
+                                 gx * (p.ostride ? p.ostride : gStride)) * p.ldc + col_off;
                         else
                             o = ((n * (2 * p.gp) + 2 * gy) * (2 * p.gq) + 2 * gx) * p.ko + col_off;
-                    } else if (FWDLIKE && !PWC && p.perm_n > 0 && !slab_rows) {
+                    } else if (FWDLIKE && !GEO && gPermN > 0 && !slab_rows) {
                         // position-major GEMM row -> (image, position) row of the NHWC tensor
                         // (split-K slabs stay indexed by GEMM row; the slab-sum kernel maps)
                         const PermRow pr = perm_row(row < p.M ? row : 0, p.gp * p.gq);
-                        o = pr.n < p.perm_n ? (pr.n * (p.gp * p.gq) + pr.pos) * p.ldc + col_off : -1;
+                        o = pr.n < gPermN ? (pr.n * (p.gp * p.gq) + pr.pos) * p.ldc + col_off : -1;
                     } else {
                         o = (row - e_row0) * e_ldc + col_off;
                     }
@@ -1607,13 +1617,21 @@ int g_w8_min_k = 256; // mrcnn_set_tuning("w8_min_k"): shallowest K (input chann
 int g_w8 = 1;         // mrcnn_set_tuning("w8", 0/1): 256x128 tiles on 512-thread workgroups (W8) for the large
                       // pointwise forward-form launches of the split-operand arithmetic
 
-int g_pw = 1;         // mrcnn_set_tuning("pw", 0/1): the PW instantiations for pointwise forward-form launches
+int g_pw = 3;         // mrcnn_set_tuning("pw"): bit 0 = the PW instantiations for pointwise forward-form launches,
+                      // bit 1 = the K3 instantiations for the 3x3 / stride 1 / pad 1 ones
 
 // PW's launch rule (see the note above conv_gemm_kernel)
 inline bool pw_plain(const GemmParams &p)
 {
     return p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.perm_n == 0 && !p.stem && p.gp == p.sh &&
            p.gq == p.sw && p.out_mode == OUT_PLAIN;
+}
+
+// K3's launch rule
+inline bool k3_plain(const GemmParams &p)
+{
+    return p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.perm_n == 0 && !p.stem &&
+           p.out_mode == OUT_PLAIN;
 }
 
 template <int TM, int TN, int MODE, bool MASKED>
@@ -1661,8 +1679,12 @@ void launch_kernel_m(const GemmParams &p0, int64_t tiles, int splits, hipStream_
     }
     if constexpr (MODE == FWD && TM == TN && (TM == 1 || TM == 2)) {
         if (g_split_bf16 & (TM == 2 ? 1 : 2)) {
-            if (g_pw && pw_plain(p))
+            if ((g_pw & 1) && pw_plain(p))
                 hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true, false, true>),
+                                      dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1,
+                                      0, p);
+            else if ((g_pw & 2) && k3_plain(p))
+                hipExtLaunchKernelGGL((conv_gemm_kernel<TM, TN, MODE, MASKED, false, true, false, false, true>),
                                       dim3((unsigned)tiles, splits, batch), dim3(256), g_extra_lds, s, ev0, ev1,
                                       0, p);
             else
