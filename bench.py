@@ -338,14 +338,16 @@ def pmc_traffic(kernel_name, split=False):
     mode = {'FWD': 0, 'DGRAD': 1, 'WGRAD': 2}[m.group(3)]
     # profiler kinds follow the kernel symbols; the unmasked variant (<.., false, false, SPLIT, W8>)
     # is what the train step runs
-    key = 'conv_gemm_kernel<%s, %s, %d, false, false, %s, %s>' % (
+    # (since round 6f the symbols carry two more arguments, PW and K3: W8 has neither; the other kinds
+    # run as three symbols — the first one the summary holds stands for the kind)
+    key = re.compile(r'conv_gemm_kernel<%s, %s, %d, false, false, %s, %s(, (true|false), (true|false))?>' % (
         m.group(1), m.group(2), mode, 'true' if split or m.group(4) else 'false',
-        'true' if m.group(4) else 'false')
+        'true' if m.group(4) else 'false'))
     for path in reversed(files):          # newest summary that holds this symbol
         with open(path) as f:
             data = json.load(f)
         for k, v in data.items():
-            if key in k and v.get('WRITE_SIZE_KB_per_launch') is not None:
+            if key.search(k) and v.get('WRITE_SIZE_KB_per_launch') is not None:
                 return dict(bytes_per_launch=round((2.0 * v['FETCH_SIZE_KB_per_launch'] +
                                                     v['WRITE_SIZE_KB_per_launch']) * 1024.0),
                             source=os.path.basename(path))

@@ -7,13 +7,17 @@ import csv, re, sys
 def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
-    m = re.match(r'conv_gemm_kernel<(\d), (\d), (\d), (\w+), (\w+)(?:, (\w+))?(?:, (\d))?>', name)
+    # <TM, TN, MODE, MASKED, WPERM, SPLIT, W8, PW, K3>
+    m = re.match(r'conv_gemm_kernel<(\d), (\d), (\d), (\w+), (\w+)(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?'
+                 r'(?:, (\w+))?>', name)
     if m:
-        return 'gemm<%s%s,%s%s%s%s%s>' % (m.group(1), m.group(2), 'FDW'[int(m.group(3))],
-                                         ',M' if m.group(4) == 'true' else '',
-                                         ',P' if m.group(5) == 'true' else '',
-                                         ',S' if m.group(6) == 'true' else '',
-                                         ',pl%s' % m.group(7) if m.group(7) not in (None, '0') else '')
+        return 'gemm<%s%s,%s%s%s%s%s%s%s>' % (m.group(1), m.group(2), 'FDW'[int(m.group(3))],
+                                             ',M' if m.group(4) == 'true' else '',
+                                             ',P' if m.group(5) == 'true' else '',
+                                             ',S' if m.group(6) == 'true' else '',
+                                             ',W8' if m.group(7) == 'true' else '',
+                                             ',PW' if m.group(8) == 'true' else '',
+                                             ',K3' if m.group(9) == 'true' else '')
     name = re.sub(r'at::native::', 'at::', name)
     return name.split('(')[0][:60]
 
