@@ -231,10 +231,18 @@ int64_t mrcnn_conv2d_split_workspace_bytes(void);
  *   (tests/test_gpu_split_bf16.py, tests/test_split_arithmetic_cpu.py).
  *   "big_min_tiles" (default 384): fewest 128x128 tiles for which the 128x128 kernels are used
  *   (1 forces them; lets small test problems exercise the kernels of the full-size step).
- *   "big_split_k" (default 0 = off): with -1, a small-M, K-deep forward-form problem whose 128x128
- *   tiles cut along K fill one round of the resident workgroups (the batch-2 res4 3x3 layers) runs
- *   that way, slabs summed in order by the epilogue kernel, instead of as 64x64 tiles; k > 0 = aim
- *   at k workgroups (probe).  Summation order differs between the settings (each deterministic). */
+ *   "big_split_k" (default -1 since round 6): with -1, a small-M, K-deep forward-form problem whose
+ *   128x128 tiles cut along K fill one round of the resident workgroups (the batch-2 res4 3x3 layers)
+ *   runs that way, slabs summed in order by the epilogue kernel, instead of as 64x64 tiles; 0 = off;
+ *   k > 0 = aim at k workgroups (probe); "big_split_min_slices" (default 16): fewest K slices per slab.
+ *   "tiny_split" (default 1): launches of <= 128 tiles and >= 32 K slices are cut along K.
+ *   Summation order differs between these settings (each deterministic).
+ * Kernel selection, results bit-identical either way (round 6):
+ *   "w8" (default 1): large pointwise forward-form launches of the split arithmetic (K >= "w8_min_k",
+ *   default 256, and at least 768 tiles) on 256x128 tiles / 512-thread workgroups.
+ *   "pw" (default 3): bit 0 = pointwise (1x1 / stride 1) forward-form launches, bit 1 = 3x3 / stride 1 /
+ *   pad 1 ones run instantiations with that geometry as compile-time constants.
+ *   "roi_fwd_lanes" / "roi_bwd_lanes" (default 256): lanes per ROIAlign workgroup. */
 int mrcnn_set_tuning(const char *name, int value);
 int mrcnn_conv2d_fwd(const mrcnn_conv_desc *d, const float *x, const float *w,
                      const float *bias, const float *scale, const float *shift,
